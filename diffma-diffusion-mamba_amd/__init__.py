@@ -1,0 +1,13 @@
+"""diffma-diffusion-mamba_amd -- MI355X-native DiffMa denoiser hot path.
+
+Import name: `diffma_amd` (the directory name carries a hyphen; the top-level `diffma_amd/` shim maps
+the importable name onto this directory).  Layout:
+
+  csrc/                       hand-written gfx950 HIP kernels + the C ABI (include/diffma_hip.h)
+  _lib.py, hip_ops.py         ctypes binding and allocation-explicit launch wrappers
+  selective_scan_interface.py reference-facing operators: selective_scan_fn, mamba_inner_fn, ...
+  mamba.py, mamba_block.py    Mamba mixer ('spiral') and Spiral_MambaBlock  (block/mamba.py, block/mamba_block.py)
+  model.py, tools.py          DiffMa, DiffMa_models, spiral()               (model.py, tools.py)
+  diffusion/                  create_diffusion / GaussianDiffusion           (diffusion/*)
+"""
+__version__ = "0.1.0"

@@ -1,0 +1,252 @@
+// K3/K4  dm_gather_conv1d_fwd / _bwd -- token gather + causal depthwise conv1d (+bias, +SiLU).
+//
+// Replaces, in one HBM pass, CrossScan's `x[:, :, order]` gathers (block/mamba.py:26-45) and
+// causal_conv1d_cuda.causal_conv1d_fwd/bwd (inside mamba_inner_fn, call sites block/mamba.py:346-348;
+// mathematics SURVEY.md A.1 step 2).
+//
+// Layout: token-major.  One lane per channel, one wave per (direction, batch, 64 channels, chunk of
+// CH time steps).  The permutation is a gather of whole 256-B row segments, so it costs nothing; a
+// chunk issues all CH+W-1 row loads up front (deep memory-level parallelism), then slides the W-tap
+// window through registers.  Algorithmic bytes: read x once per direction + write out = 2*s B/element
+// per direction (halo re-reads of W-1 rows per chunk are L2 hits).
+#include "dm_common.h"
+
+namespace dm {
+
+constexpr int CONV_CH = 14;   // time steps per wave chunk (196 = 14*14)
+
+template <typename T, typename TW, int W, bool SILU>
+__global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) {
+    const int lane = threadIdx.x;
+    const int d0 = blockIdx.x * WAVE;
+    const int c = blockIdx.y;
+    const int s = blockIdx.z;               // dir*batch + b
+    const int dir = s / p.batch;
+    const int b = s - dir * p.batch;
+    const int L = p.seqlen;
+    const bool active = (d0 + lane) < p.dim;
+    const int d = active ? d0 + lane : p.dim - 1;
+    const int lbeg = c * CONV_CH;
+
+    const T* __restrict__ xp = (const T*)p.x + (int64_t)b * p.x_sb + d;
+    T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss + d;
+    const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
+
+    float w[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) w[j] = io<TW>::ld((const TW*)p.weight + (int64_t)d * W + j);
+    const float bias = p.bias ? io<TW>::ld((const TW*)p.bias + d) : 0.0f;
+
+    // rows lbeg-(W-1) .. lbeg+CH-1 ; out-of-range rows contribute zero
+    T raw[CONV_CH + W - 1];
+#pragma unroll
+    for (int j = 0; j < CONV_CH + W - 1; ++j) {
+        int l = lbeg - (W - 1) + j;
+        l = l < 0 ? 0 : (l >= L ? L - 1 : l);
+        const int r = idx ? idx[l] : l;
+        raw[j] = xp[(int64_t)r * p.x_sl];
+    }
+    float xv[CONV_CH + W - 1];
+#pragma unroll
+    for (int j = 0; j < CONV_CH + W - 1; ++j) {
+        const int l = lbeg - (W - 1) + j;
+        xv[j] = (l >= 0) ? io<T>::ld(&raw[j]) : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < CONV_CH; ++j) {
+        const int l = lbeg + j;
+        if (l < L) {
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc += w[k] * xv[j + k];
+            if (SILU) acc = silu_f(acc);
+            if (active) io<T>::st(op + (int64_t)l * p.o_sl, acc);
+        }
+    }
+}
+
+// Backward: g[m] = dout[m]*act'(pre[m]);  dxs[m] = sum_j w[j]*g[m+W-1-j]  written at token idx[m];
+// dw[j] += g[m]*x[idx[m-(W-1)+j]];  db += g[m].   A chunk needs pre/g on [lbeg, lbeg+CH+W-1) and x
+// on [lbeg-(W-1), lbeg+CH+W-1).
+template <typename T, typename TW, int W, bool SILU>
+__global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) {
+    const int lane = threadIdx.x;
+    const int d0 = blockIdx.x * WAVE;
+    const int c = blockIdx.y;
+    const int s = blockIdx.z;
+    const int dir = s / p.batch;
+    const int b = s - dir * p.batch;
+    const int L = p.seqlen;
+    const bool active = (d0 + lane) < p.dim;
+    const int d = active ? d0 + lane : p.dim - 1;
+    const int lbeg = c * CONV_CH;
+    constexpr int NG = CONV_CH + W - 1;        // g positions lbeg .. lbeg+NG-1
+    constexpr int NX = CONV_CH + 2 * (W - 1);  // x positions lbeg-(W-1) .. lbeg+NG-1
+
+    const T* __restrict__ xp = (const T*)p.x + (int64_t)b * p.x_sb + d;
+    const T* __restrict__ gp = (const T*)p.dout + (int64_t)s * p.do_ss + d;
+    T* __restrict__ dxp = (T*)p.dx + (int64_t)s * p.dx_ss + d;
+    const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
+
+    float w[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) w[j] = io<TW>::ld((const TW*)p.weight + (int64_t)d * W + j);
+    const float bias = p.bias ? io<TW>::ld((const TW*)p.bias + d) : 0.0f;
+
+    T rawx[NX], rawg[NG];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        int l = lbeg - (W - 1) + j;
+        l = l < 0 ? 0 : (l >= L ? L - 1 : l);
+        const int r = idx ? idx[l] : l;
+        rawx[j] = xp[(int64_t)r * p.x_sl];
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        int l = lbeg + j;
+        l = l >= L ? L - 1 : l;
+        rawg[j] = gp[(int64_t)l * p.do_sl];
+    }
+    float xv[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        const int l = lbeg - (W - 1) + j;
+        xv[j] = (l >= 0 && l < L) ? io<T>::ld(&rawx[j]) : 0.0f;
+    }
+    float g[NG];
+    float dw[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) dw[j] = 0.0f;
+    float db = 0.0f;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const int l = lbeg + j;
+        float gv = 0.0f;
+        if (l < L) {
+            gv = io<T>::ld(&rawg[j]);
+            if (SILU) {
+                float pre = bias;
+#pragma unroll
+                for (int k = 0; k < W; ++k) pre += w[k] * xv[j + k];
+                const float sg = sigmoid_f(pre);
+                gv *= sg * (1.0f + pre * (1.0f - sg));
+            }
+            if (j < CONV_CH) {   // each position's parameter gradient is owned by exactly one chunk
+#pragma unroll
+                for (int k = 0; k < W; ++k) dw[k] += gv * xv[j + k];
+                db += gv;
+            }
+        }
+        g[j] = gv;
+    }
+#pragma unroll
+    for (int j = 0; j < CONV_CH; ++j) {
+        const int m = lbeg + j;
+        if (m < L) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < W; ++k) acc += w[k] * g[j + (W - 1) - k];
+            const int r = idx ? idx[m] : m;
+            if (active) io<T>::st(dxp + (int64_t)r * p.dx_sl, acc);
+        }
+    }
+    if (active) {
+        float* dwp = p.dw_partial + (((int64_t)s * p.nchunk + c) * p.dim + d) * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) dwp[k] = dw[k];
+        if (p.db_partial) p.db_partial[((int64_t)s * p.nchunk + c) * p.dim + d] = db;
+    }
+}
+
+template <typename T, typename TW, int W>
+static int launch_conv_fwd(const dm_conv_fwd_args& a, hipStream_t st) {
+    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
+    dim3 grid((a.dim + WAVE - 1) / WAVE, nchunk, a.ndir * a.batch), block(WAVE);
+    if (a.flags & DM_FLAG_SILU)
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, false>), grid, block, 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_gather_conv1d_fwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+
+template <typename T, typename TW, int W>
+static int launch_conv_bwd(const dm_conv_bwd_args& a, hipStream_t st) {
+    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
+    dim3 grid((a.dim + WAVE - 1) / WAVE, nchunk, a.ndir * a.batch), block(WAVE);
+    if (a.flags & DM_FLAG_SILU)
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, false>), grid, block, 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_gather_conv1d_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+
+template <typename T, typename TW, typename Args, int (*F2)(const Args&, hipStream_t), int (*F3)(const Args&, hipStream_t),
+          int (*F4)(const Args&, hipStream_t)>
+static int by_width(const Args& a, hipStream_t st, const char* who) {
+    switch (a.width) {
+        case 2: return F2(a, st);
+        case 3: return F3(a, st);
+        case 4: return F4(a, st);
+        default: set_error("%s: width %d not in {2,3,4}", who, a.width); return DM_ERR_ARG;
+    }
+}
+
+template <typename T, typename TW>
+static int conv_fwd_t(const dm_conv_fwd_args& a, hipStream_t st) {
+    return by_width<T, TW, dm_conv_fwd_args, launch_conv_fwd<T, TW, 2>, launch_conv_fwd<T, TW, 3>,
+                    launch_conv_fwd<T, TW, 4>>(a, st, "dm_gather_conv1d_fwd");
+}
+template <typename T, typename TW>
+static int conv_bwd_t(const dm_conv_bwd_args& a, hipStream_t st) {
+    return by_width<T, TW, dm_conv_bwd_args, launch_conv_bwd<T, TW, 2>, launch_conv_bwd<T, TW, 3>,
+                    launch_conv_bwd<T, TW, 4>>(a, st, "dm_gather_conv1d_bwd");
+}
+
+}  // namespace dm
+
+extern "C" int dm_conv_nchunk(int seqlen) { return (seqlen + dm::CONV_CH - 1) / dm::CONV_CH; }
+
+extern "C" int dm_gather_conv1d_fwd(const dm_conv_fwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_gather_conv1d_fwd: null args"); return DM_ERR_ARG; }
+    const dm_conv_fwd_args& a = *args;
+    if (!a.x || !a.weight || !a.out) { set_error("dm_gather_conv1d_fwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_fwd: non-positive size"); return DM_ERR_ARG; }
+    if ((int64_t)a.ndir * a.batch > 65535) { set_error("dm_gather_conv1d_fwd: ndir*batch > 65535"); return DM_ERR_ARG; }
+    if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_fwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
+    if (a.x_sd != 1 || a.o_sd != 1) { set_error("dm_gather_conv1d_fwd: needs token-major tensors (channel stride 1)"); return DM_ERR_LAYOUT; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool wf32 = a.w_dtype == DM_F32;
+    if (!wf32 && a.w_dtype != a.io_dtype) { set_error("dm_gather_conv1d_fwd: w_dtype must be fp32 or io_dtype"); return DM_ERR_DTYPE; }
+    switch (a.io_dtype) {
+        case DM_F32: return conv_fwd_t<float, float>(a, st);
+        case DM_BF16: return wf32 ? conv_fwd_t<bf16_t, float>(a, st) : conv_fwd_t<bf16_t, bf16_t>(a, st);
+        case DM_F16: return wf32 ? conv_fwd_t<f16_t, float>(a, st) : conv_fwd_t<f16_t, f16_t>(a, st);
+        default: set_error("dm_gather_conv1d_fwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
+    }
+}
+
+extern "C" int dm_gather_conv1d_bwd(const dm_conv_bwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_gather_conv1d_bwd: null args"); return DM_ERR_ARG; }
+    const dm_conv_bwd_args& a = *args;
+    if (!a.x || !a.weight || !a.dout || !a.dx || !a.dw_partial) { set_error("dm_gather_conv1d_bwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_bwd: non-positive size"); return DM_ERR_ARG; }
+    if ((int64_t)a.ndir * a.batch > 65535) { set_error("dm_gather_conv1d_bwd: ndir*batch > 65535"); return DM_ERR_ARG; }
+    if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_bwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
+    if (a.nchunk != dm_conv_nchunk(a.seqlen)) { set_error("dm_gather_conv1d_bwd: nchunk must be dm_conv_nchunk(seqlen)"); return DM_ERR_ARG; }
+    if (a.x_sd != 1 || a.do_sd != 1 || a.dx_sd != 1) { set_error("dm_gather_conv1d_bwd: needs token-major tensors"); return DM_ERR_LAYOUT; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool wf32 = a.w_dtype == DM_F32;
+    if (!wf32 && a.w_dtype != a.io_dtype) { set_error("dm_gather_conv1d_bwd: w_dtype must be fp32 or io_dtype"); return DM_ERR_DTYPE; }
+    switch (a.io_dtype) {
+        case DM_F32: return conv_bwd_t<float, float>(a, st);
+        case DM_BF16: return wf32 ? conv_bwd_t<bf16_t, float>(a, st) : conv_bwd_t<bf16_t, bf16_t>(a, st);
+        case DM_F16: return wf32 ? conv_bwd_t<f16_t, float>(a, st) : conv_bwd_t<f16_t, f16_t>(a, st);
+        default: set_error("dm_gather_conv1d_bwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
+    }
+}

@@ -1,0 +1,79 @@
+// Shared device helpers for the DiffMa gfx950 kernels.  CDNA4 only: wave64, no portability shims.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/diffma_hip.h"
+
+namespace dm {
+
+constexpr int WAVE = 64;
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- storage types -------------------------------------------------------------------------
+struct bf16_t { uint16_t v; };
+struct f16_t { _Float16 v; };
+
+template <typename T> struct io;
+template <> struct io<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float x) { *p = x; }
+};
+template <> struct io<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) {
+        return __uint_as_float(((uint32_t)p->v) << 16);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, float x) {
+        // round-to-nearest-even, NaN preserved
+        uint32_t u = __float_as_uint(x);
+        uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+        if ((u & 0x7FFFFFFFu) > 0x7F800000u) r = u | 0x00400000u;
+        p->v = (uint16_t)(r >> 16);
+    }
+};
+template <> struct io<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)p->v; }
+    static __device__ __forceinline__ void st(f16_t* p, float x) { p->v = (_Float16)x; }
+};
+
+// Wave-uniform read-only operands (B_l, C_l rows, index tables) are read through the CONSTANT address
+// space: a uniform constant-space load is selected as s_load_dword* (scalar cache -> SGPRs) instead of a
+// 64-lane broadcast vector load.  Legal because nothing in a launch writes these buffers.
+template <typename T> using cptr = const T __attribute__((address_space(4)))*;
+template <typename T> __device__ __forceinline__ cptr<T> as_const(const T* p) {
+    return (cptr<T>)(uintptr_t)p;
+}
+template <typename T> struct cio;
+template <> struct cio<float> { static __device__ __forceinline__ float ld(cptr<float> p) { return *p; } };
+template <> struct cio<bf16_t> {
+    static __device__ __forceinline__ float ld(cptr<bf16_t> p) { return __uint_as_float(((uint32_t)p->v) << 16); }
+};
+template <> struct cio<f16_t> { static __device__ __forceinline__ float ld(cptr<f16_t> p) { return (float)p->v; } };
+
+// ---- transcendental helpers (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp, no range fix-ups) ----
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// softplus(x) = log(1+e^x); identity above 20 like the reference operator.
+__device__ __forceinline__ float softplus_f(float x) {
+    float e = fast_exp2(x * LOG2E);
+    float big = fast_log2(1.0f + e) * LN2;
+    float small = e * (1.0f - 0.5f * e);          // log1p series, exact to fp32 for e < 2^-12
+    float r = (e < 2.44140625e-4f) ? small : big;
+    return (x > 20.0f) ? x : r;
+}
+__device__ __forceinline__ float sigmoid_f(float x) {
+    return fast_rcp(1.0f + fast_exp2(-x * LOG2E));
+}
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+
+// thread-local error string (host side)
+void set_error(const char* fmt, ...);
+
+}  // namespace dm

@@ -1,0 +1,85 @@
+// K5  dm_token_merge -- out[b][t][:] = sum_k in[k][b][idx_k[t]][:]
+//
+// Replaces CrossMerge / merge_permutation (block/mamba.py:29-30, 59-69) applied BEFORE out_proj, and
+// is the 3-slab gradient sum of the backward pass (CrossScan.backward, block/mamba.py:47-57).
+// Pure HBM streaming: (nin reads + 1 write) * s bytes per output element, 16-B vector accesses,
+// whole rows are gathered so the permutation is free.
+#include "dm_common.h"
+
+namespace dm {
+
+template <typename TI, typename TO, int VEC>
+__global__ __launch_bounds__(256) void merge_kernel(const dm_merge_args p) {
+    // grid.x covers dim/VEC vectors of one row in blocks of 256 threads; grid.y = seqlen; grid.z = batch
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    const int b = blockIdx.z;
+    if (v * VEC >= p.dim) return;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+    for (int k = 0; k < p.nin; ++k) {
+        const int r = p.row_index ? p.row_index[(int64_t)k * p.seqlen + t] : t;
+        const TI* src = (const TI*)p.in + (int64_t)k * p.in_sk + (int64_t)b * p.in_sb + (int64_t)r * p.in_sl + (int64_t)v * VEC;
+        alignas(16) TI tmp[VEC];
+        if (VEC == 4 && sizeof(TI) == 4) {
+            *(f32x4*)tmp = *(const f32x4*)src;
+        } else if (VEC == 8 && sizeof(TI) == 2) {
+            *(f32x4*)tmp = *(const f32x4*)src;
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) tmp[j] = src[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += io<TI>::ld(&tmp[j]);
+    }
+    alignas(16) TO outv[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) io<TO>::st(&outv[j], acc[j]);
+    TO* dst = (TO*)p.out + (int64_t)b * p.o_sb + (int64_t)t * p.o_sl + (int64_t)v * VEC;
+    if (VEC * sizeof(TO) == 16) {
+        *(f32x4*)dst = *(const f32x4*)outv;
+    } else if (VEC * sizeof(TO) == 8) {
+        *(f32x2*)dst = *(const f32x2*)outv;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = outv[j];
+    }
+}
+
+template <typename TI, typename TO>
+static int launch_merge(const dm_merge_args& a, hipStream_t st) {
+    constexpr int VECMAX = 16 / sizeof(TI);
+    const bool vec_ok = (a.dim % VECMAX == 0) && (a.in_sk % VECMAX == 0) && (a.in_sb % VECMAX == 0) &&
+                        (a.in_sl % VECMAX == 0) && (a.o_sb % VECMAX == 0) && (a.o_sl % VECMAX == 0) &&
+                        (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.out) % 16 == 0);
+    if (vec_ok) {
+        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch);
+        hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch);
+        hipLaunchKernelGGL((merge_kernel<TI, TO, 1>), grid, dim3(256), 0, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_token_merge: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+
+}  // namespace dm
+
+extern "C" int dm_token_merge(const dm_merge_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_token_merge: null args"); return DM_ERR_ARG; }
+    const dm_merge_args& a = *args;
+    if (!a.in || !a.out) { set_error("dm_token_merge: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.nin <= 0 || a.batch <= 0 || a.seqlen <= 0 || a.dim <= 0) { set_error("dm_token_merge: non-positive size"); return DM_ERR_ARG; }
+    if (a.batch > 65535 || a.seqlen > 65535) { set_error("dm_token_merge: batch/seqlen > 65535"); return DM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    if (a.io_dtype == DM_F32 && a.out_dtype == DM_F32) return launch_merge<float, float>(a, st);
+    if (a.io_dtype == DM_BF16 && a.out_dtype == DM_BF16) return launch_merge<bf16_t, bf16_t>(a, st);
+    if (a.io_dtype == DM_F16 && a.out_dtype == DM_F16) return launch_merge<f16_t, f16_t>(a, st);
+    if (a.io_dtype == DM_F32 && a.out_dtype == DM_BF16) return launch_merge<float, bf16_t>(a, st);
+    if (a.io_dtype == DM_F32 && a.out_dtype == DM_F16) return launch_merge<float, f16_t>(a, st);
+    set_error("dm_token_merge: unsupported dtype pair (%d -> %d)", a.io_dtype, a.out_dtype);
+    return DM_ERR_DTYPE;
+}

@@ -1,0 +1,279 @@
+// K1  dm_selective_scan_fwd -- Mamba-1 selective scan, forward, for gfx950 (MI355X).
+//
+// Replaces selective_scan_cuda.fwd behind selective_scan_fn / mamba_inner_fn
+// (reference call sites block/mamba.py:11, 346-348; mathematics SURVEY.md A.1 step 4).
+//
+// Design (CDNA4-first, not the upstream CUDA tiling):
+//   * token-major tensors [seq][l][d]: ONE LANE PER CHANNEL, one wave64 per 64 channels of one
+//     sequence.  Every per-step access of the wave is a single coalesced 256-B row segment, so there
+//     is no LDS transposition and no cross-lane traffic at all.
+//   * the recurrence runs sequentially in time inside the lane with the d_state states held in
+//     registers (packed f32x2 -> v_pk_mul/v_pk_fma): per (b,d,l) element that is N exp2 + ~2.5N packed
+//     VALU ops, i.e. the work-optimal count -- a wave-parallel associative (Blelloch) scan of the same
+//     recurrence costs ~2.5x the VALU work and is ALU-bound below the HBM roof.
+//   * B_l / C_l are shared by all channels of a sequence: they are wave-uniform, fetched through the
+//     scalar cache into SGPRs (s_load_dwordx8/16), and used directly as packed-FMA operands.
+//   * latency hiding comes from a register prefetch ring of PF time steps (u, delta, z rows are
+//     requested PF steps before use), not from occupancy: at batch 64 there is one wave per SIMD.
+//   * CrossScan's z gather and CrossMerge's inverse reindex are folded into the row addressing
+//     (z_row_index / out_row_index), so the (B,3,2D,L) buffer of block/mamba.py:41 never exists.
+#include "dm_common.h"
+
+namespace dm {
+
+// Wave-uniform B_l / C_l rows -> SGPRs (scalar cache).  Issued one step ahead of their use.
+template <typename TBC, int N>
+__device__ __forceinline__ void load_bc(float (&Bv)[N], float (&Cv)[N], const TBC* Bp, const TBC* Cp, int64_t bsl,
+                                        int64_t csl, int l) {
+    const cptr<TBC> Bl = as_const(Bp + (int64_t)l * bsl);
+    const cptr<TBC> Cl = as_const(Cp + (int64_t)l * csl);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        Bv[k] = cio<TBC>::ld(Bl + k);
+        Cv[k] = cio<TBC>::ld(Cl + k);
+    }
+}
+
+// One time step of the recurrence for one lane.
+template <typename T, typename TBC, int N, bool HAS_Z, bool SOFTPLUS>
+__device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[N / 2], const float (&Bv)[N],
+                                           const float (&Cv)[N], float uu, float draw, float zz, float Dv,
+                                           float bias) {
+    float dl = draw + bias;
+    if (SOFTPLUS) dl = softplus_f(dl);
+    const float du = dl * uu;
+    f32x2 acc = (f32x2){0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < N / 2; ++k) {
+        const f32x2 t = A2[k] * dl;
+        f32x2 a;
+        a.x = fast_exp2(t.x);
+        a.y = fast_exp2(t.y);
+        f32x2 bb, cc;
+        bb.x = Bv[2 * k];
+        bb.y = Bv[2 * k + 1];
+        cc.x = Cv[2 * k];
+        cc.y = Cv[2 * k + 1];
+        h[k] = a * h[k] + bb * du;
+        acc += h[k] * cc;
+    }
+    float y = acc.x + acc.y + Dv * uu;
+    if (HAS_Z) y *= silu_f(zz);
+    return y;
+}
+
+// IDX : z_row_index / out_row_index tables are used (both non-null)
+// CKPT: h is written to p.ckpt every p.ckpt_every steps (a multiple of PF)
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF>
+__global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+    static_assert(N % 2 == 0, "d_state must be even");
+    constexpr int NP = N / 2;
+    const int d = blockIdx.x * WAVE + threadIdx.x;
+    if (d >= p.dim) return;   // no cross-lane traffic anywhere below: idle lanes simply leave
+    const int s = blockIdx.y;
+    const int L = p.seqlen;
+
+    const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
+    const int dir = s / bpd;
+    const int sb = s - dir * bpd;
+    const int grp = (blockIdx.x * WAVE) / (p.dim / p.ngroups);
+
+    const T* __restrict__ up = (const T*)p.u + (int64_t)s * p.u_ss + d;
+    const T* __restrict__ dp = (const T*)p.delta + (int64_t)s * p.dt_ss + d;
+    const T* __restrict__ zp = HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss + d : nullptr;
+    T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss + d;
+    const TBC* Bp = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
+    const TBC* Cp = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
+    const cptr<int32_t> zidx = IDX ? as_const(p.z_row_index + (int64_t)dir * L) : nullptr;
+    const cptr<int32_t> oidx = IDX ? as_const(p.out_row_index + (int64_t)dir * L) : nullptr;
+
+    // per-channel constants: A pre-scaled by log2(e) so that exp(delta*A) = v_exp_f32(delta*A2)
+    f32x2 A2[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        A2[j].x = p.A[(int64_t)d * N + 2 * j] * LOG2E;
+        A2[j].y = p.A[(int64_t)d * N + 2 * j + 1] * LOG2E;
+    }
+    const float Dv = p.D ? p.D[d] : 0.0f;
+    const float bias = p.delta_bias ? p.delta_bias[d] : 0.0f;
+
+    f32x2 h[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) h[j] = (f32x2){0.0f, 0.0f};
+
+    const int K = CKPT ? p.ckpt_every : 1;
+    const int nchunk = CKPT ? (L + K - 1) / K : 0;
+
+    // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
+    T ru[PF], rd[PF], rz[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int l = (j < L) ? j : L - 1;
+        ru[j] = up[(int64_t)l * p.u_sl];
+        rd[j] = dp[(int64_t)l * p.dt_sl];
+        if (HAS_Z) rz[j] = zp[(int64_t)(IDX ? zidx[l] : l) * p.z_sl];
+    }
+
+    float Bc[N], Cc[N];
+    load_bc<TBC, N>(Bc, Cc, Bp, Cp, p.B_sl, p.C_sl, 0);
+
+    const int Lfull = (L / PF) * PF;
+    for (int l0 = 0; l0 < Lfull; l0 += PF) {
+        T nu[PF], nd[PF], nz[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            int l = l0 + PF + j;
+            l = (l < L) ? l : L - 1;
+            nu[j] = up[(int64_t)l * p.u_sl];
+            nd[j] = dp[(int64_t)l * p.dt_sl];
+            if (HAS_Z) nz[j] = zp[(int64_t)(IDX ? zidx[l] : l) * p.z_sl];
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int l = l0 + j;
+            float Bn[N], Cn[N];
+            {
+                const int ln = (l + 1 < L) ? l + 1 : L - 1;
+                load_bc<TBC, N>(Bn, Cn, Bp, Cp, p.B_sl, p.C_sl, ln);
+            }
+            const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
+                                                                  HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
+            io<T>::st(op + (int64_t)(IDX ? oidx[l] : l) * p.o_sl, y);
+#pragma unroll
+            for (int k = 0; k < N; ++k) { Bc[k] = Bn[k]; Cc[k] = Cn[k]; }
+        }
+        if (CKPT) {
+            const int done = l0 + PF;                 // steps finished; wave-uniform
+            if (done % K == 0 && done < L) {          // state entering chunk done/K
+                float* ck = p.ckpt + (((int64_t)s * nchunk + done / K) * N) * p.dim + d;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    ck[(int64_t)(2 * k) * p.dim] = h[k].x;
+                    ck[(int64_t)(2 * k + 1) * p.dim] = h[k].y;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            ru[j] = nu[j];
+            rd[j] = nd[j];
+            if (HAS_Z) rz[j] = nz[j];
+        }
+    }
+    // tail (< PF steps); its rows are already in the ring
+#pragma unroll
+    for (int j = 0; j < PF; ++j) {
+        const int l = Lfull + j;
+        if (l < L) {
+            const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
+                                                                  HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
+            io<T>::st(op + (int64_t)(IDX ? oidx[l] : l) * p.o_sl, y);
+            const int ln = (l + 1 < L) ? l + 1 : L - 1;
+            load_bc<TBC, N>(Bc, Cc, Bp, Cp, p.B_sl, p.C_sl, ln);
+        }
+    }
+
+    if (p.last_state) {
+        float* ls = p.last_state + ((int64_t)s * N) * p.dim + d;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            ls[(int64_t)(2 * k) * p.dim] = h[k].x;
+            ls[(int64_t)(2 * k + 1) * p.dim] = h[k].y;
+        }
+    }
+}
+
+constexpr int SCAN_PF = 8;
+
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
+static void launch_fwd3(const dm_scan_fwd_args& a, hipStream_t st, dim3 grid) {
+    const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
+    if (a.ckpt) {
+        if (sp) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, true, true, SCAN_PF>), grid, dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, true, false, SCAN_PF>), grid, dim3(WAVE), 0, st, a);
+    } else {
+        if (sp) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, false, true, SCAN_PF>), grid, dim3(WAVE), 0, st, a);
+        else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, false, false, SCAN_PF>), grid, dim3(WAVE), 0, st, a);
+    }
+}
+
+template <typename T, typename TBC, int N>
+static int launch_fwd(const dm_scan_fwd_args& a, hipStream_t st) {
+    dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq);
+    const bool idx = a.z_row_index != nullptr;   // validated: both tables or neither
+    if (a.z) {
+        if (idx) launch_fwd3<T, TBC, N, true, true>(a, st, grid);
+        else launch_fwd3<T, TBC, N, true, false>(a, st, grid);
+    } else {
+        if (idx) launch_fwd3<T, TBC, N, false, true>(a, st, grid);
+        else launch_fwd3<T, TBC, N, false, false>(a, st, grid);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("dm_selective_scan_fwd: launch failed: %s", hipGetErrorString(e));
+        return DM_ERR_LAUNCH;
+    }
+    return DM_OK;
+}
+
+template <typename T, typename TBC>
+static int dispatch_n(const dm_scan_fwd_args& a, hipStream_t st) {
+    switch (a.dstate) {
+        case 16: return launch_fwd<T, TBC, 16>(a, st);
+#ifndef DM_FAST_BUILD
+        case 8: return launch_fwd<T, TBC, 8>(a, st);
+        case 32: return launch_fwd<T, TBC, 32>(a, st);
+        case 64: return launch_fwd<T, TBC, 64>(a, st);
+#endif
+        default:
+            set_error("dm_selective_scan_fwd: d_state=%d not instantiated (8,16,32,64)", a.dstate);
+            return DM_ERR_DSTATE;
+    }
+}
+
+template <typename T>
+static int dispatch_bc(const dm_scan_fwd_args& a, hipStream_t st) {
+    // B/C either share the I/O dtype or are fp32 (keeps the instantiation count bounded)
+    if (a.bc_dtype == DM_F32) return dispatch_n<T, float>(a, st);
+    if (a.bc_dtype == a.io_dtype) return dispatch_n<T, T>(a, st);
+    set_error("dm_selective_scan_fwd: bc_dtype %d must be fp32 or equal io_dtype %d", a.bc_dtype, a.io_dtype);
+    return DM_ERR_DTYPE;
+}
+
+}  // namespace dm
+
+extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_selective_scan_fwd: null args"); return DM_ERR_ARG; }
+    const dm_scan_fwd_args& a = *args;
+    if (!a.u || !a.delta || !a.out || !a.A || !a.B || !a.C) {
+        set_error("dm_selective_scan_fwd: null tensor pointer"); return DM_ERR_ARG;
+    }
+    if (a.nseq <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ngroups <= 0) {
+        set_error("dm_selective_scan_fwd: non-positive size"); return DM_ERR_ARG;
+    }
+    if (a.nseq > 65535) { set_error("dm_selective_scan_fwd: nseq %d > 65535", a.nseq); return DM_ERR_ARG; }
+    if (a.u_sd != 1 || a.dt_sd != 1 || a.o_sd != 1 || (a.z && a.z_sd != 1) || a.B_sn != 1 || a.C_sn != 1) {
+        set_error("dm_selective_scan_fwd: needs token-major tensors (channel stride 1, state stride 1)");
+        return DM_ERR_LAYOUT;
+    }
+    if (a.dim % a.ngroups != 0 || (a.ngroups > 1 && (a.dim / a.ngroups) % WAVE != 0)) {
+        set_error("dm_selective_scan_fwd: dim/ngroups must be a multiple of 64"); return DM_ERR_LAYOUT;
+    }
+    if (a.batch_per_dir > 0 && a.nseq % a.batch_per_dir != 0) {
+        set_error("dm_selective_scan_fwd: nseq %% batch_per_dir != 0"); return DM_ERR_ARG;
+    }
+    if (a.ckpt && (a.ckpt_every <= 0 || a.ckpt_every % SCAN_PF != 0)) {
+        set_error("dm_selective_scan_fwd: ckpt_every must be a positive multiple of %d", SCAN_PF); return DM_ERR_ARG;
+    }
+    if ((a.z_row_index == nullptr) != (a.out_row_index == nullptr)) {
+        set_error("dm_selective_scan_fwd: z_row_index and out_row_index must both be set or both be NULL"); return DM_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.io_dtype) {
+        case DM_F32: return dispatch_bc<float>(a, st);
+        case DM_BF16: return dispatch_bc<bf16_t>(a, st);
+        case DM_F16: return dispatch_bc<f16_t>(a, st);
+        default: set_error("dm_selective_scan_fwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
+    }
+}

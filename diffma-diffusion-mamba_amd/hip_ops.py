@@ -1,0 +1,219 @@
+"""Thin, allocation-explicit wrappers over the C ABI (include/diffma_hip.h).
+
+Everything here works on TOKEN-MAJOR tensors ([seq, L, D], channel stride 1) -- the layout the
+gfx950 kernels are written for -- and on raw device pointers + the current torch stream.  The
+reference-facing operator names live in selective_scan_interface.py.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_SILU, dm_conv_bwd_args,
+                   dm_conv_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+
+_DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
+SCAN_CKPT_EVERY = 16   # steps between saved states in training mode (multiple of the kernel's PF=8)
+
+
+def dtype_code(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {t.dtype}; the kernels take fp32, bf16 or fp16") from None
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "DiffMa HIP operators need tensors on a ROCm device; there is no CPU implementation in "
+                "the product path (the CPU oracle under oracle/ is test infrastructure only)")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _f32c(t):
+    """fp32 contiguous view/copy of a small parameter tensor."""
+    if t is None:
+        return None
+    return t.detach().to(torch.float32).contiguous()
+
+
+def scan_nchunk(L: int, every: int = SCAN_CKPT_EVERY) -> int:
+    return (L + every - 1) // every
+
+
+def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
+             z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
+             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1):
+    """u, delta: [S, L, Dm] token-major (last stride 1).  Bm, Cm: [S, L, G*N] views (state stride 1).
+    z: [S or S/ndir, Lz, Dm] or None.  A: [Dm, N] fp32.  Returns out [S, L, Dm] (allocated if None)."""
+    _require_gpu(u, delta, A, Bm, Cm, z)
+    S, L, Dm = u.shape
+    N = A.shape[1]
+    if out is None:
+        out = torch.empty((S, L, Dm), dtype=u.dtype, device=u.device)
+    A = _f32c(A)
+    D = _f32c(D)
+    delta_bias = _f32c(delta_bias)
+    a = dm_scan_fwd_args()
+    a.nseq, a.dim, a.seqlen, a.dstate = S, Dm, L, N
+    a.ngroups = ngroups
+    a.batch_per_dir = batch_per_dir
+    a.io_dtype = dtype_code(u)
+    a.bc_dtype = dtype_code(Bm)
+    a.flags = DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0
+    a.ckpt_every = ckpt_every
+    a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
+    a.B, a.C, a.A, a.D, a.delta_bias = _ptr(Bm), _ptr(Cm), _ptr(A), _ptr(D), _ptr(delta_bias)
+    a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
+    a.ckpt, a.last_state = _ptr(ckpt), _ptr(last_state)
+    a.u_ss, a.u_sl, a.u_sd = u.stride()
+    a.dt_ss, a.dt_sl, a.dt_sd = delta.stride()
+    if z is not None:
+        a.z_ss, a.z_sl, a.z_sd = z.stride()
+    a.o_ss, a.o_sl, a.o_sd = out.stride()
+    a.B_ss, a.B_sl, a.B_sn = Bm.stride()
+    a.C_ss, a.C_sl, a.C_sn = Cm.stride()
+    a.B_sg = a.C_sg = N
+    with torch.cuda.device(u.device):
+        _lib.call("dm_selective_scan_fwd", a, _stream(u))
+    return out
+
+
+def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
+             z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
+             ngroups=1, dz_out=None):
+    """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
+    already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
+    z_row_index is given)."""
+    _require_gpu(u, delta, A, Bm, Cm, z, dout, ckpt)
+    S, L, Dm = u.shape
+    N = A.shape[1]
+    nw = (Dm + 63) // 64
+    dev = u.device
+    A32, D32, b32 = _f32c(A), _f32c(D), _f32c(delta_bias)
+    du = torch.empty_like(u)
+    ddelta = torch.empty((S, L, Dm), dtype=u.dtype, device=dev)
+    dz = None
+    if z is not None:
+        dz = dz_out if dz_out is not None else torch.empty((S, L, Dm), dtype=u.dtype, device=dev)
+    dBC = torch.empty((S, L, nw, 2 * N), dtype=torch.float32, device=dev)
+    dA = torch.empty((S, Dm, N), dtype=torch.float32, device=dev)
+    dD = torch.empty((S, Dm), dtype=torch.float32, device=dev) if D is not None else None
+    dbias = torch.empty((S, Dm), dtype=torch.float32, device=dev) if delta_bias is not None else None
+    a = dm_scan_bwd_args()
+    a.nseq, a.dim, a.seqlen, a.dstate = S, Dm, L, N
+    a.ngroups = ngroups
+    a.batch_per_dir = batch_per_dir
+    a.io_dtype = dtype_code(u)
+    a.bc_dtype = dtype_code(Bm)
+    a.flags = DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0
+    a.ckpt_every = ckpt_every
+    a.u, a.delta, a.z, a.dout = _ptr(u), _ptr(delta), _ptr(z), _ptr(dout)
+    a.B, a.C, a.A, a.D, a.delta_bias = _ptr(Bm), _ptr(Cm), _ptr(A32), _ptr(D32), _ptr(b32)
+    a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
+    a.ckpt = _ptr(ckpt)
+    a.du, a.ddelta, a.dz = _ptr(du), _ptr(ddelta), _ptr(dz)
+    a.dBC_partial, a.dA_partial = _ptr(dBC), _ptr(dA)
+    a.dD_partial, a.dbias_partial = _ptr(dD), _ptr(dbias)
+    a.u_ss, a.u_sl, a.u_sd = u.stride()
+    a.dt_ss, a.dt_sl, a.dt_sd = delta.stride()
+    if z is not None:
+        a.z_ss, a.z_sl, a.z_sd = z.stride()
+        a.dz_ss, a.dz_sl, a.dz_sd = dz.stride()
+    a.do_ss, a.do_sl, a.do_sd = dout.stride()
+    a.B_ss, a.B_sl, a.B_sn = Bm.stride()
+    a.C_ss, a.C_sl, a.C_sn = Cm.stride()
+    a.B_sg = a.C_sg = N
+    a.du_ss, a.du_sl, a.du_sd = du.stride()
+    a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
+    with torch.cuda.device(dev):
+        _lib.call("dm_selective_scan_bwd", a, _stream(u))
+    dBCs = dBC.sum(dim=2)                       # [S, L, 2N] fp32, deterministic
+    dB, dC = dBCs[..., :N], dBCs[..., N:]
+    return (du, ddelta, dz, dB, dC, dA.sum(0), dD.sum(0) if dD is not None else None,
+            dbias.sum(0) if dbias is not None else None)
+
+
+def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out=None):
+    """x: [B, L, Dm] token-major view (e.g. xz[..., :Dm]); weight [Dm, W]; -> [ndir*B, L, Dm]."""
+    _require_gpu(x, weight, bias)
+    Bsz, L, Dm = x.shape
+    W = weight.shape[-1]
+    weight = weight.reshape(Dm, W).contiguous()
+    if weight.dtype != x.dtype and weight.dtype != torch.float32:
+        weight = weight.float()
+    if bias is not None:
+        bias = bias.to(weight.dtype).contiguous()
+    if out is None:
+        out = torch.empty((ndir * Bsz, L, Dm), dtype=x.dtype, device=x.device)
+    a = dm_conv_fwd_args()
+    a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
+    a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
+    a.flags = DM_FLAG_SILU if silu else 0
+    a.x, a.weight, a.bias, a.row_index, a.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index), _ptr(out)
+    a.x_sb, a.x_sl, a.x_sd = x.stride()
+    a.o_ss, a.o_sl, a.o_sd = out.stride()
+    with torch.cuda.device(x.device):
+        _lib.call("dm_gather_conv1d_fwd", a, _stream(x))
+    return out
+
+
+def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=True):
+    """Returns (dx_slabs [ndir*B, L, Dm] in token order, dweight [Dm, W] fp32, dbias [Dm] fp32)."""
+    _require_gpu(x, weight, bias, dout)
+    Bsz, L, Dm = x.shape
+    W = weight.shape[-1]
+    weight = weight.reshape(Dm, W).contiguous()
+    if weight.dtype != x.dtype and weight.dtype != torch.float32:
+        weight = weight.float()
+    if bias is not None:
+        bias = bias.to(weight.dtype).contiguous()
+    lib = _lib.load()
+    nchunk = lib.dm_conv_nchunk(L)
+    dev = x.device
+    dx = torch.empty((ndir * Bsz, L, Dm), dtype=x.dtype, device=dev)
+    dw = torch.empty((ndir * Bsz, nchunk, Dm, W), dtype=torch.float32, device=dev)
+    db = torch.empty((ndir * Bsz, nchunk, Dm), dtype=torch.float32, device=dev)
+    a = dm_conv_bwd_args()
+    a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
+    a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
+    a.flags = DM_FLAG_SILU if silu else 0
+    a.nchunk = nchunk
+    a.x, a.weight, a.bias, a.dout = _ptr(x), _ptr(weight), _ptr(bias), _ptr(dout)
+    a.row_index = _ptr(row_index)
+    a.dx, a.dw_partial, a.db_partial = _ptr(dx), _ptr(dw), _ptr(db)
+    a.x_sb, a.x_sl, a.x_sd = x.stride()
+    a.do_ss, a.do_sl, a.do_sd = dout.stride()
+    a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
+    with torch.cuda.device(dev):
+        _lib.call("dm_gather_conv1d_bwd", a, _stream(x))
+    return dx, dw.sum(dim=(0, 1)), db.sum(dim=(0, 1))
+
+
+def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
+    """slabs: [K, B, L, Dm] (last stride 1) -> out [B, L, Dm] = sum_k slabs[k][:, idx_k, :]."""
+    _require_gpu(slabs)
+    K, Bsz, L, Dm = slabs.shape
+    if out is None:
+        out = torch.empty((Bsz, L, Dm), dtype=out_dtype or slabs.dtype, device=slabs.device)
+    assert slabs.stride(3) == 1 and out.stride(2) == 1
+    a = dm_merge_args()
+    a.nin, a.batch, a.seqlen, a.dim = K, Bsz, L, Dm
+    a.io_dtype, a.out_dtype = dtype_code(slabs), dtype_code(out)
+    a.row_index = _ptr(row_index)
+    a.out = _ptr(out)
+    setattr(a, "in", _ptr(slabs))
+    a.in_sk, a.in_sb, a.in_sl = slabs.stride()[:3]
+    a.o_sb, a.o_sl = out.stride()[:2]
+    with torch.cuda.device(slabs.device):
+        _lib.call("dm_token_merge", a, _stream(slabs))
+    return out

@@ -1,0 +1,214 @@
+/*
+ * diffma_hip.h -- C ABI of libdiffma_hip.so (MI355X / gfx950 kernels for the DiffMa hot path).
+ *
+ * The reference (wongzbb/DiffMa-Diffusion-Mamba) has no C ABI of its own: its hot path sits behind
+ * Python operator functions imported by name from two un-vendored CUDA wheels
+ *   block/mamba.py:11      from mamba_ssm.ops.selective_scan_interface import selective_scan_fn, mamba_inner_fn
+ *   block/mamba.py:13      from causal_conv1d import causal_conv1d_fn
+ *   block/mamba.py:26-82   scan_permutation / merge_permutation / CrossScan / CrossMerge (token reindex)
+ * Each entry point below names the reference interface it replaces.  The Python operator mirror
+ * (diffma-diffusion-mamba_amd/selective_scan_interface.py) binds these with ctypes.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; every buffer (inputs, outputs, workspaces) is owned by the
+ *     caller; the library allocates nothing and keeps no references.
+ *   - all pointers are DEVICE pointers; strides are in ELEMENTS (not bytes), 64-bit.
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous, never synchronise, and are
+ *     legal inside hipGraph capture.
+ *   - return 0 on success, a negative dm_status on failure; dm_last_error() returns a thread-local
+ *     message for the last failure.  Nothing throws across the ABI.
+ *   - "token-major" ("channel-last") layout means the channel stride is 1:  x[b][l][d].  The kernels are
+ *     written for that layout (one lane per channel, coalesced 256-B wave rows); DM_ERR_LAYOUT is returned
+ *     for anything else and the host shim repacks.
+ */
+#ifndef DIFFMA_HIP_H
+#define DIFFMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DM_ABI_VERSION 3
+
+typedef enum {
+    DM_OK = 0,
+    DM_ERR_ARG = -1,     /* null pointer / bad size                        */
+    DM_ERR_LAYOUT = -2,  /* stride pattern the kernel does not implement   */
+    DM_ERR_DTYPE = -3,   /* unsupported dtype enum                         */
+    DM_ERR_DSTATE = -4,  /* d_state not in the instantiated set            */
+    DM_ERR_LAUNCH = -5   /* hipLaunchKernel reported an error              */
+} dm_status;
+
+typedef enum { DM_F32 = 0, DM_BF16 = 1, DM_F16 = 2 } dm_dtype;
+
+enum {
+    DM_FLAG_DELTA_SOFTPLUS = 1, /* delta = softplus(delta + bias)                     */
+    DM_FLAG_SILU = 2            /* conv: apply SiLU after the bias add                */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * Selective scan, forward.   Replaces selective_scan_cuda.fwd behind
+ *   selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus)   (block/mamba.py:11)
+ * and the scan stage of mamba_inner_fn (call sites block/mamba.py:346-348).
+ *
+ *   delta' = softplus(delta + delta_bias[d])            (if DM_FLAG_DELTA_SOFTPLUS)
+ *   h[n]   = exp(delta'*A[d][n]) * h[n] + delta'*B[s][l][n]*u        h[-1] = 0
+ *   y      = sum_n C[s][l][n]*h[n] + D[d]*u ;   out = y * silu(z)    (z optional)
+ *
+ * Sequences: nseq = ndir * batch_per_dir.  u/delta/out/B/C are indexed by the sequence index s;
+ * z is indexed by (s % batch_per_dir) and, when z_row_index != NULL, read at row
+ * z_row_index[dir*seqlen + l]  (dir = s / batch_per_dir): the CrossScan gather of the z half is folded
+ * into the load (block/mamba.py:32-45).  When out_row_index != NULL the result of step l is stored at
+ * row out_row_index[dir*seqlen + l]: the CrossMerge inverse reindex is folded into the store
+ * (block/mamba.py:59-69).  With ndir = 1 and both index pointers NULL this is the plain operator.
+ *
+ * ckpt (optional, training): h after every ckpt_every steps, fp32, layout [s][chunk][n][d].
+ * last_state (optional): final h, fp32, layout [s][n][d].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nseq, dim, seqlen, dstate;
+    int32_t ngroups;         /* B/C groups over the channel axis (DiffMa: 1)           */
+    int32_t batch_per_dir;   /* nseq = ndir*batch_per_dir; 0 or nseq means ndir = 1    */
+    int32_t io_dtype;        /* dm_dtype of u, delta, z, out                           */
+    int32_t bc_dtype;        /* dm_dtype of B, C                                       */
+    int32_t flags;
+    int32_t ckpt_every;      /* steps between checkpoints (only read when ckpt != 0)   */
+    const void *u, *delta, *z;   /* z may be NULL */
+    void *out;
+    const void *B, *C;
+    const float *A;          /* [dim][dstate] fp32, contiguous */
+    const float *D;          /* [dim] fp32 or NULL             */
+    const float *delta_bias; /* [dim] fp32 or NULL             */
+    const int32_t *z_row_index;   /* [ndir][seqlen] or NULL */
+    const int32_t *out_row_index; /* [ndir][seqlen] or NULL */
+    float *ckpt;             /* or NULL */
+    float *last_state;       /* or NULL */
+    /* element strides; the channel stride of u/delta/z/out and the state stride of B/C must be 1 */
+    int64_t u_ss, u_sl, u_sd;
+    int64_t dt_ss, dt_sl, dt_sd;
+    int64_t z_ss, z_sl, z_sd;
+    int64_t o_ss, o_sl, o_sd;
+    int64_t B_ss, B_sl, B_sg, B_sn;
+    int64_t C_ss, C_sl, C_sg, C_sn;
+} dm_scan_fwd_args;
+
+int dm_selective_scan_fwd(const dm_scan_fwd_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Selective scan, backward.  Replaces selective_scan_cuda.bwd (autograd of the above; training path
+ * train.py:259).  Consumes the forward's checkpoints, recomputes the states of one chunk at a time in
+ * registers and runs the adjoint recurrence in reverse time (equations: SURVEY.md A.1-bwd).
+ *
+ *   dout is read at row out_row_index[dir][l] (the gather that is the adjoint of the forward's scatter),
+ *   dz is written at row z_row_index[dir][l] of a per-direction buffer [s][row][d].
+ *   dB/dC: per-wave partial sums over 64 channels, fp32, layout [s][l][dim/64][2*dstate] (B then C);
+ *   dA: [s][dim][dstate], dD: [s][dim], ddelta_bias: [s][dim]  fp32 per-sequence partials.
+ *   The caller reduces the partials (deterministic; no atomics).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nseq, dim, seqlen, dstate;
+    int32_t ngroups;
+    int32_t batch_per_dir;
+    int32_t io_dtype;
+    int32_t bc_dtype;
+    int32_t flags;
+    int32_t ckpt_every;
+    const void *u, *delta, *z, *dout;
+    const void *B, *C;
+    const float *A, *D, *delta_bias;
+    const int32_t *z_row_index;
+    const int32_t *out_row_index;
+    const float *ckpt;       /* required */
+    void *du, *ddelta, *dz;  /* dz NULL iff z NULL; same dtype as u */
+    float *dBC_partial;      /* [nseq][seqlen][dim/64][2*dstate] */
+    float *dA_partial;       /* [nseq][dim][dstate]              */
+    float *dD_partial;       /* [nseq][dim] or NULL              */
+    float *dbias_partial;    /* [nseq][dim] or NULL              */
+    int64_t u_ss, u_sl, u_sd;
+    int64_t dt_ss, dt_sl, dt_sd;
+    int64_t z_ss, z_sl, z_sd;
+    int64_t do_ss, do_sl, do_sd;
+    int64_t B_ss, B_sl, B_sg, B_sn;
+    int64_t C_ss, C_sl, C_sg, C_sn;
+    int64_t du_ss, du_sl, du_sd;
+    int64_t ddt_ss, ddt_sl, ddt_sd;
+    int64_t dz_ss, dz_sl, dz_sd;
+} dm_scan_bwd_args;
+
+int dm_selective_scan_bwd(const dm_scan_bwd_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token gather + causal depthwise conv1d (+bias, +SiLU), forward.  Replaces
+ *   CrossScan / scan_permutation     block/mamba.py:26-45   (xs[:,k] = x[:, :, order_k])
+ *   causal_conv1d_cuda.causal_conv1d_fwd  (causal_conv1d_fn, block/mamba.py:13; inside mamba_inner_fn)
+ * in one pass:  out[dir][b][l][d] = act(bias[d] + sum_j w[d][j] * x[b][ idx[dir][l-(W-1)+j] ][d])
+ * with terms at l-(W-1)+j < 0 dropped (left zero padding).  row_index == NULL means identity, ndir = 1.
+ * x: [batch][seqlen][*] token-major view (x_sd must be 1); out: [ndir*batch][seqlen][dim] token-major.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, dim, seqlen, width, ndir;
+    int32_t io_dtype, w_dtype;
+    int32_t flags;
+    const void *x;
+    const void *weight;       /* [dim][width], w_dtype, contiguous */
+    const void *bias;         /* [dim] or NULL, w_dtype            */
+    const int32_t *row_index; /* [ndir][seqlen] or NULL            */
+    void *out;
+    int64_t x_sb, x_sl, x_sd;
+    int64_t o_ss, o_sl, o_sd;
+} dm_conv_fwd_args;
+
+int dm_gather_conv1d_fwd(const dm_conv_fwd_args *args, void *stream);
+
+/* Backward of the above (CrossScan.backward block/mamba.py:47-57 + causal_conv1d_bwd).
+ *   dx_dir[dir][b][ idx[dir][m] ][d] = sum_j w[d][j] * g[dir][b][m+(W-1)-j][d],   g = dout * act'(pre)
+ * i.e. the gradient of every direction is written back in TOKEN order (the scatter through idx is the
+ * adjoint of the gather); the caller sums the ndir slabs with dm_token_merge.
+ *   dw_partial: [ndir*batch][nchunk][dim][width] fp32, db_partial: [ndir*batch][nchunk][dim] fp32.
+ */
+typedef struct {
+    int32_t batch, dim, seqlen, width, ndir;
+    int32_t io_dtype, w_dtype;
+    int32_t flags;
+    int32_t nchunk;           /* = dm_conv_nchunk(seqlen) */
+    const void *x, *weight, *bias, *dout;
+    const int32_t *row_index;
+    void *dx;                 /* [ndir*batch][seqlen][dim], io_dtype, token order */
+    float *dw_partial, *db_partial;
+    int64_t x_sb, x_sl, x_sd;
+    int64_t do_ss, do_sl, do_sd;
+    int64_t dx_ss, dx_sl, dx_sd;
+} dm_conv_bwd_args;
+
+int dm_gather_conv1d_bwd(const dm_conv_bwd_args *args, void *stream);
+int dm_conv_nchunk(int seqlen);
+
+/* ------------------------------------------------------------------------------------------------
+ * Token merge: out[b][t][c] = sum_k in[k][b][ idx[k][t] ][c]     (idx NULL = identity).
+ * Replaces CrossMerge / merge_permutation  block/mamba.py:29-30,59-69 applied BEFORE out_proj
+ * (out_proj is linear and bias-free, block/mamba.py:240,315, so sum-then-project == project-then-sum
+ * up to rounding) and serves as the 3-slab gradient sum of the backward pass.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nin, batch, seqlen, dim;
+    int32_t io_dtype, out_dtype;
+    const void *in;            /* [nin][batch][seqlen][dim] via strides */
+    const int32_t *row_index;  /* [nin][seqlen] or NULL */
+    void *out;
+    int64_t in_sk, in_sb, in_sl;   /* channel stride 1 */
+    int64_t o_sb, o_sl;
+} dm_merge_args;
+
+int dm_token_merge(const dm_merge_args *args, void *stream);
+
+/* Library introspection. */
+int dm_abi_version(void);
+const char *dm_last_error(void);
+const char *dm_build_info(void);   /* "gfx950 hipcc <ver> <date>" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFMA_HIP_H */
