@@ -23,10 +23,10 @@ namespace dm {
 
 // Wave-uniform B_l / C_l rows -> SGPRs (scalar cache).  Issued one step ahead of their use.
 template <typename TBC, int N>
-__device__ __forceinline__ void load_bc(float (&Bv)[N], float (&Cv)[N], const TBC* Bp, const TBC* Cp, int64_t bsl,
-                                        int64_t csl, int l) {
-    const cptr<TBC> Bl = as_const(Bp + (int64_t)l * bsl);
-    const cptr<TBC> Cl = as_const(Cp + (int64_t)l * csl);
+__device__ __forceinline__ void load_bc(float (&Bv)[N], float (&Cv)[N], const TBC* Bp, const TBC* Cp, int bsl,
+                                        int csl, int l) {
+    const cptr<TBC> Bl = as_const(Bp + l * bsl);
+    const cptr<TBC> Cl = as_const(Cp + l * csl);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         Bv[k] = cio<TBC>::ld(Bl + k);
@@ -72,6 +72,13 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
     if (d >= p.dim) return;   // no cross-lane traffic anywhere below: idle lanes simply leave
     const int s = blockIdx.y;
     const int L = p.seqlen;
+    // in-sequence row offsets fit 32 bits (validated by the host entry point)
+    const int i_B_sl = (int)p.B_sl;
+    const int i_C_sl = (int)p.C_sl;
+    const int i_dt_sl = (int)p.dt_sl;
+    const int i_o_sl = (int)p.o_sl;
+    const int i_u_sl = (int)p.u_sl;
+    const int i_z_sl = (int)p.z_sl;
 
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
     const int dir = s / bpd;
@@ -109,13 +116,13 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         const int l = (j < L) ? j : L - 1;
-        ru[j] = up[(int64_t)l * p.u_sl];
-        rd[j] = dp[(int64_t)l * p.dt_sl];
-        if (HAS_Z) rz[j] = zp[(int64_t)(IDX ? zidx[l] : l) * p.z_sl];
+        ru[j] = up[l * i_u_sl];
+        rd[j] = dp[l * i_dt_sl];
+        if (HAS_Z) rz[j] = zp[(IDX ? zidx[l] : l) * i_z_sl];
     }
 
     float Bc[N], Cc[N];
-    load_bc<TBC, N>(Bc, Cc, Bp, Cp, p.B_sl, p.C_sl, 0);
+    load_bc<TBC, N>(Bc, Cc, Bp, Cp, i_B_sl, i_C_sl, 0);
 
     const int Lfull = (L / PF) * PF;
     for (int l0 = 0; l0 < Lfull; l0 += PF) {
@@ -124,9 +131,9 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
         for (int j = 0; j < PF; ++j) {
             int l = l0 + PF + j;
             l = (l < L) ? l : L - 1;
-            nu[j] = up[(int64_t)l * p.u_sl];
-            nd[j] = dp[(int64_t)l * p.dt_sl];
-            if (HAS_Z) nz[j] = zp[(int64_t)(IDX ? zidx[l] : l) * p.z_sl];
+            nu[j] = up[l * i_u_sl];
+            nd[j] = dp[l * i_dt_sl];
+            if (HAS_Z) nz[j] = zp[(IDX ? zidx[l] : l) * i_z_sl];
         }
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -134,11 +141,11 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
             float Bn[N], Cn[N];
             {
                 const int ln = (l + 1 < L) ? l + 1 : L - 1;
-                load_bc<TBC, N>(Bn, Cn, Bp, Cp, p.B_sl, p.C_sl, ln);
+                load_bc<TBC, N>(Bn, Cn, Bp, Cp, i_B_sl, i_C_sl, ln);
             }
             const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
                                                                   HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
-            io<T>::st(op + (int64_t)(IDX ? oidx[l] : l) * p.o_sl, y);
+            io<T>::st(op + (IDX ? oidx[l] : l) * i_o_sl, y);
 #pragma unroll
             for (int k = 0; k < N; ++k) { Bc[k] = Bn[k]; Cc[k] = Cn[k]; }
         }
@@ -167,9 +174,9 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
         if (l < L) {
             const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
                                                                   HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
-            io<T>::st(op + (int64_t)(IDX ? oidx[l] : l) * p.o_sl, y);
+            io<T>::st(op + (IDX ? oidx[l] : l) * i_o_sl, y);
             const int ln = (l + 1 < L) ? l + 1 : L - 1;
-            load_bc<TBC, N>(Bc, Cc, Bp, Cp, p.B_sl, p.C_sl, ln);
+            load_bc<TBC, N>(Bc, Cc, Bp, Cp, i_B_sl, i_C_sl, ln);
         }
     }
 

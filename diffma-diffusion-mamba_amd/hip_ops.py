@@ -13,7 +13,7 @@ from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_SILU
                    dm_conv_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
-SCAN_CKPT_EVERY = 16   # steps between saved states in training mode (multiple of the kernel's PF=8)
+SCAN_CKPT_EVERY = 8    # steps between saved states in training mode (= BWD_CK of scan_bwd.hip)
 
 
 def dtype_code(t: torch.Tensor) -> int:

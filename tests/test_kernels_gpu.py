@@ -172,3 +172,117 @@ def test_token_merge_exact(gpu):
     torch.testing.assert_close(out, ref)
     out2 = hip_ops.token_merge(slabs.to(gpu)).cpu()
     assert torch.equal(out2, (slabs[0] + slabs[1]) + slabs[2])
+
+
+def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None):
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import selective_scan_ref
+
+    host, d = _inputs(S, L, Dm, N, dtype, seed=seed, dev=gpu, with_z=with_z and not indexed)
+    g = torch.Generator().manual_seed(seed + 1)
+    K = hip_ops.SCAN_CKPT_EVERY
+    nch = hip_ops.scan_nchunk(L, K)
+    ckpt = torch.zeros(S, nch, N, Dm, device=gpu)
+    kw = {}
+    if indexed:
+        ndir = S // Bsz
+        zsrc = torch.randn(Bsz, L, Dm, generator=g).to(dtype)
+        zperm = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+        operm = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+        kw = dict(z_row_index=zperm.to(gpu), out_row_index=operm.to(gpu), batch_per_dir=Bsz)
+        zdev = zsrc.to(gpu)
+        dout = torch.randn(Bsz, L, Dm, generator=g).to(dtype)   # gradient of the MERGED output (token order)
+    else:
+        zdev = d["z"]
+        dout = torch.randn(S, L, Dm, generator=g).to(dtype)
+    out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], True,
+                           ckpt=ckpt, ckpt_every=K, **kw)
+    res = hip_ops.scan_bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], dout.to(gpu), ckpt,
+                           True, ckpt_every=K, **kw)
+    torch.cuda.synchronize()
+    du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
+
+    # fp64 autograd of the oracle on the same (rounded) inputs
+    leaf = lambda t: t.float().double().clone().requires_grad_(True)
+    u, dl, A, Bm, Cm, Dp, bias = leaf(host["u"]), leaf(host["delta"]), leaf(host["A"]), leaf(host["B"]), leaf(host["C"]), leaf(host["D"]), leaf(host["bias"])
+    cm = lambda t: t.permute(0, 2, 1)
+    if indexed:
+        z = leaf(zsrc)
+        ndir = S // Bsz
+        zs = torch.cat([z[:, zperm[k].long(), :] for k in range(ndir)], 0)        # [S, L, Dm] gathered
+        y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=cm(zs), delta_bias=bias, delta_softplus=True))
+        # scatter: merged[b, operm[k][l]] += y[k*Bsz+b, l]
+        merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+        for k in range(ndir):
+            merged = merged.index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
+        loss = (merged * dout.float().double()).sum()
+    else:
+        z = leaf(host["z"]) if with_z else None
+        y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=None if z is None else cm(z), delta_bias=bias,
+                                  delta_softplus=True))
+        loss = (y * dout.float().double()).sum()
+    loss.backward()
+    rtol, atol = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (4e-2, 6e-2)}[dtype]
+
+    def chk(got, ref, name, sum_scale=1.0):
+        sc = max(1.0, ref.abs().max().item())
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol * sc * sum_scale, msg=lambda m: f"{name}: {m}")
+
+    chk(du, u.grad, "du")
+    chk(ddelta, dl.grad, "ddelta")
+    if indexed:
+        # dz slabs are per direction in token order: sum them
+        chk(dz.view(S // Bsz, Bsz, L, Dm).sum(0), z.grad, "dz")
+    elif with_z:
+        chk(dz, z.grad, "dz")
+    chk(dB, Bm.grad, "dB", 4.0)
+    chk(dC, Cm.grad, "dC", 4.0)
+    chk(dA, A.grad, "dA", 4.0)
+    chk(dD, Dp.grad, "dD", 4.0)
+    chk(dbias, bias.grad, "dbias", 4.0)
+
+
+@pytest.mark.parametrize("S,L,Dm", [(2, 196, 256), (3, 49, 128), (2, 16, 64), (1, 13, 200), (2, 1, 64)])
+def test_scan_bwd_matches_oracle_autograd(gpu, S, L, Dm):
+    _scan_bwd_case(gpu, torch.float32, S, L, Dm, 16, seed=L + Dm)
+
+
+def test_scan_bwd_no_z(gpu):
+    _scan_bwd_case(gpu, torch.float32, 2, 29, 128, 16, seed=9, with_z=False)
+
+
+def test_scan_bwd_bf16(gpu):
+    _scan_bwd_case(gpu, torch.bfloat16, 2, 40, 128, 16, seed=4)
+
+
+def test_scan_bwd_indexed_three_directions(gpu):
+    _scan_bwd_case(gpu, torch.float32, 6, 37, 128, 16, seed=21, indexed=True, Bsz=2)
+
+
+@pytest.mark.parametrize("Bsz,L,Dm,W", [(2, 196, 256, 4), (2, 30, 128, 4), (1, 5, 200, 3), (1, 1, 64, 4)])
+def test_gather_conv_bwd_matches_oracle_autograd(gpu, Bsz, L, Dm, W):
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import causal_conv1d_ref
+
+    g = torch.Generator().manual_seed(L + Dm + W)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g)
+    w = torch.randn(Dm, W, generator=g) * 0.5
+    b = torch.randn(Dm, generator=g) * 0.1
+    ndir = 3
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    dout = torch.randn(ndir * Bsz, L, Dm, generator=g)
+    dx, dw, db = hip_ops.gather_conv1d_bwd(xz.to(gpu)[..., :Dm], w.to(gpu), b.to(gpu), dout.to(gpu),
+                                          row_index=perms.to(gpu), ndir=ndir)
+    torch.cuda.synchronize()
+    x = xz[..., :Dm].double().clone().requires_grad_(True)
+    wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    loss = 0
+    for k in range(ndir):
+        xs = x[:, perms[k].long(), :]
+        y = causal_conv1d_ref(xs.permute(0, 2, 1), wd, bd, activation="silu").permute(0, 2, 1)
+        loss = loss + (y * dout.view(ndir, Bsz, L, Dm)[k].double()).sum()
+    loss.backward()
+    torch.testing.assert_close(dx.cpu().double().view(ndir, Bsz, L, Dm).sum(0), x.grad, rtol=1e-4, atol=1e-5)
+    sc = max(1.0, wd.grad.abs().max().item())
+    torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=1e-4, atol=2e-5 * sc)
+    torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=1e-4, atol=2e-5 * sc)
