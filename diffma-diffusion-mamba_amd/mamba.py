@@ -1,0 +1,82 @@
+"""Mamba-1 mixer of DiffMa, 'spiral' scan (reference block/mamba.py:226-355), MI355X-native.
+
+State-dict keys and constructor arguments match the reference class so its checkpoints load:
+    in_proj.weight (2*Din, d_model)   conv1d.weight (Din, 1, d_conv)   conv1d.bias (Din)
+    x_proj.weight (R+2N, Din)         dt_proj.weight (Din, R)          dt_proj.bias (Din)
+    A_log (Din, N)   D (Din)          out_proj.weight (d_model, Din)
+Differences in HOW (not WHAT): activations stay token-major end to end, the three scan directions are one
+fused operator (selective_scan_interface.spiral_ssm), the permutations are int32 device buffers built
+once (the reference re-uploads Python lists on every call, block/mamba.py:27,30), and the merge happens
+before out_proj so there is one projection GEMM instead of three.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .selective_scan_interface import spiral_ssm
+
+
+class Mamba(nn.Module):
+    def __init__(self, d_model, d_state=16, d_conv=4, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, conv_bias=True, bias=False,
+                 use_fast_path=True, layer_idx=None, device=None, dtype=None, token_list=(),
+                 token_list_reversal=(), origina_list=(), origina_list_reversal=()):
+        fk = {"device": device, "dtype": dtype}
+        super().__init__()
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        self.layer_idx = layer_idx
+        self.in_proj = nn.Linear(d_model, 2 * self.d_inner, bias=bias, **fk)
+        self.conv1d = nn.Conv1d(self.d_inner, self.d_inner, kernel_size=d_conv, groups=self.d_inner,
+                                padding=d_conv - 1, bias=conv_bias, **fk)
+        self.x_proj = nn.Linear(self.d_inner, self.dt_rank + 2 * d_state, bias=False, **fk)
+        self.dt_proj = nn.Linear(self.dt_rank, self.d_inner, bias=True, **fk)
+        # dt_proj init of the Mamba paper (block/mamba.py:284-302).  DiffMa's own initialize_weights later
+        # overwrites it with xavier/zero; both are reproduced, in that order.
+        std = self.dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(self.dt_proj.weight, std)
+        elif dt_init == "random":
+            nn.init.uniform_(self.dt_proj.weight, -std, std)
+        else:
+            raise NotImplementedError(dt_init)
+        dt = torch.exp(torch.rand(self.d_inner, **fk) * (math.log(dt_max) - math.log(dt_min)) + math.log(dt_min))
+        dt = dt.clamp(min=dt_init_floor)
+        with torch.no_grad():
+            self.dt_proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))       # softplus^-1
+        self.dt_proj.bias._no_reinit = True
+        A = torch.arange(1, d_state + 1, dtype=torch.float32, device=device).repeat(self.d_inner, 1)
+        self.A_log = nn.Parameter(torch.log(A))
+        self.A_log._no_weight_decay = True
+        self.D = nn.Parameter(torch.ones(self.d_inner, device=device))
+        self.D._no_weight_decay = True
+        self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias, **fk)
+
+        self.token_list, self.token_list_reversal = list(token_list), list(token_list_reversal)
+        self.origina_list, self.origina_list_reversal = list(origina_list), list(origina_list_reversal)
+        L = len(self.token_list)
+        if L:
+            idx = torch.tensor([list(range(L)), self.token_list, self.token_list_reversal], dtype=torch.int32)
+        else:
+            idx = torch.zeros((3, 0), dtype=torch.int32)
+        # not in the state dict (the reference keeps Python lists)
+        self.register_buffer("scan_index", idx, persistent=False)
+
+    def forward(self, hidden_states, scan_type="spiral", inference_params=None):
+        """hidden_states: (B, L, d_model) -> (B, L, d_model)."""
+        if scan_type != "spiral":
+            raise NotImplementedError(f"scan_type={scan_type!r}: only the DiffMa 'spiral' path is built (SURVEY.md 8f)")
+        if inference_params is not None:
+            raise NotImplementedError("autoregressive decode is never used by a diffusion model")
+        if hidden_states.shape[1] != self.scan_index.shape[1]:
+            raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
+        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
+        A = -torch.exp(self.A_log.float())
+        y = spiral_ssm(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
+                       self.dt_proj.bias, A, self.D, self.scan_index)
+        return F.linear(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)

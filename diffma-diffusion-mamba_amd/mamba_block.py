@@ -1,0 +1,57 @@
+"""Spiral_MambaBlock: the DiffMa block (reference block/mamba_block.py:13-130).
+
+    shift, scale, gate = adaLN(c)                    x_ssm = LN(x)*(1+scale)+shift
+    w_ssm = x_ssm * w   (soft mask, w in (0,1))      x_ssm = mamba1(x_ssm); w_ssm = mamba2(w_ssm)
+    a = sigmoid(MLP(LN(cat[x_ssm, w_ssm])))          x = x + gate * (a*x_ssm + (1-a)*w_ssm)
+Sub-module names equal the reference's, so state dicts are interchangeable.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .mamba import Mamba
+
+
+def modulate(x, shift, scale):
+    return x * (1 + scale.unsqueeze(1)) + shift.unsqueeze(1)
+
+
+class Spiral_MambaBlock(nn.Module):
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, token_list, token_list_reversal,
+                 origina_list, origina_list_reversal, use_mamba2=False):
+        super().__init__()
+        self.D_dim, self.E_dim, self.dt_rank, self.dim_inner, self.d_state = D_dim, E_dim, dt_rank, dim_inner, d_state
+        lists = dict(token_list=token_list, token_list_reversal=token_list_reversal, origina_list=origina_list,
+                     origina_list_reversal=origina_list_reversal)
+        self.norm1 = nn.LayerNorm(D_dim)
+        if use_mamba2:
+            from .mamba2 import Mamba2 as mixer
+        else:
+            mixer = Mamba
+        # NB the reference does not forward dt_rank to the mixer: dt_rank = ceil(D_dim/16)
+        self.mamba1 = mixer(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, **lists)
+        self.mamba2 = mixer(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, **lists)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(2 * D_dim, 3 * D_dim, bias=True))
+        self.attention_network = nn.Sequential(nn.LayerNorm(2 * D_dim), nn.Linear(2 * D_dim, D_dim, bias=True), nn.SiLU(),
+                                               nn.Linear(D_dim, 1, bias=True), nn.Sigmoid())
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        for i in (1, 3):
+            nn.init.constant_(self.attention_network[i].weight, 0)
+            nn.init.constant_(self.attention_network[i].bias, 0)
+
+    def forward(self, x, c, w):
+        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        x_ssm = modulate(self.norm1(x), shift, scale)
+        w_ssm = x_ssm * w
+        x_ssm = self.mamba1(x_ssm, "spiral")
+        w_ssm = self.mamba2(w_ssm, "spiral")
+        a = self.attention_network(torch.cat([x_ssm, w_ssm], dim=-1))
+        return x + gate.unsqueeze(1) * (a * x_ssm + (1 - a) * w_ssm)

@@ -1,0 +1,239 @@
+"""Reference-facing operators, backed by the gfx950 kernels (C ABI: include/diffma_hip.h).
+
+Names, argument order and meaning mirror what the reference imports
+    block/mamba.py:11   from mamba_ssm.ops.selective_scan_interface import selective_scan_fn, mamba_inner_fn
+    block/mamba.py:13   from causal_conv1d import causal_conv1d_fn
+so a maintainer can point those imports here.  Tensors arrive in the reference's
+channel-major convention (B, D, L); internally everything is token-major [B, L, D] (channel stride 1),
+which is what the lane-per-channel kernels want.  A (B, D, L)-shaped *view* of a token-major buffer is
+consumed without a copy; a genuinely L-contiguous tensor is repacked once.
+
+`spiral_ssm` is the fused 3-direction operator the DiffMa mixer uses (block/mamba.py:343-355): token
+gather + conv1d + SiLU, x_proj, dt_proj, selective scan with the z gather and the CrossMerge
+inverse reindex folded into row addressing, then the 3-way merge BEFORE out_proj.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import hip_ops
+
+
+def _to_token_major(t: torch.Tensor) -> torch.Tensor:
+    """(B, D, L) in any layout -> a [B, L, D] tensor with stride(-1) == 1 (no copy when possible)."""
+    tm = t.transpose(1, 2)
+    return tm if tm.stride(-1) == 1 else tm.contiguous()
+
+
+def _bc_token_major(Bm: torch.Tensor):
+    """B/C arrive as (B, N, L) or (B, G, N, L); return ([B, L, G*N] with state stride 1, G)."""
+    if Bm.dim() == 3:
+        Bm = Bm[:, None]
+    bsz, G, N, L = Bm.shape
+    t = Bm.permute(0, 3, 1, 2)                                  # (B, L, G, N)
+    if not (t.stride(3) == 1 and t.stride(2) == N):
+        t = t.contiguous()
+    return t.reshape(bsz, L, G * N) if t.is_contiguous() else t.as_strided((bsz, L, G * N), (t.stride(0), t.stride(1), 1)), G
+
+
+class _SelectiveScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, return_last_state):
+        ut, dt = _to_token_major(u), _to_token_major(delta)
+        zt = _to_token_major(z) if z is not None else None
+        if dt.dtype != ut.dtype:
+            dt = dt.to(ut.dtype)
+        if zt is not None and zt.dtype != ut.dtype:
+            zt = zt.to(ut.dtype)
+        Bt, G = _bc_token_major(Bm)
+        Ct, _ = _bc_token_major(Cm)
+        if Bt.dtype not in (torch.float32, ut.dtype):
+            Bt = Bt.to(ut.dtype)
+        if Ct.dtype != Bt.dtype:
+            Ct = Ct.to(Bt.dtype)
+        S, L, Dm = ut.shape
+        N = A.shape[1]
+        need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+        ckpt = None
+        if need_grad:
+            ckpt = torch.empty((S, hip_ops.scan_nchunk(L), N, Dm), dtype=torch.float32, device=ut.device)
+        last = torch.empty((S, N, Dm), dtype=torch.float32, device=ut.device) if return_last_state else None
+        out = hip_ops.scan_fwd(ut, dt, A, Bt, Ct, D, zt, delta_bias, delta_softplus, ckpt=ckpt, last_state=last,
+                               ngroups=G)
+        ctx.delta_softplus = delta_softplus
+        ctx.G = G
+        ctx.has_z, ctx.has_D, ctx.has_bias = z is not None, D is not None, delta_bias is not None
+        ctx.b4, ctx.c4 = Bm.dim() == 4, Cm.dim() == 4
+        ctx.save_for_backward(ut, dt, A, Bt, Ct, D, zt, delta_bias, ckpt)
+        out_cm = out.transpose(1, 2)                            # (B, D, L) view, like the reference returns
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out_cm, last.transpose(1, 2)
+        return out_cm
+
+    @staticmethod
+    def backward(ctx, dout, *ignored):
+        ut, dt, A, Bt, Ct, D, zt, delta_bias, ckpt = ctx.saved_tensors
+        if ctx.G != 1:
+            raise NotImplementedError("backward with ngroups > 1 is not wired (DiffMa uses ngroups = 1)")
+        dot = _to_token_major(dout)
+        if dot.dtype != ut.dtype:
+            dot = dot.to(ut.dtype)
+        du, ddelta, dz, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(ut, dt, A, Bt, Ct, D, zt, delta_bias, dot, ckpt,
+                                                                 ctx.delta_softplus)
+        cm = lambda t: t.transpose(1, 2)
+        dBm = dB.to(Bt.dtype).transpose(1, 2)                   # (B, N, L)
+        dCm = dC.to(Ct.dtype).transpose(1, 2)
+        if ctx.b4:
+            dBm = dBm[:, None]
+        if ctx.c4:
+            dCm = dCm[:, None]
+        return (cm(du), cm(ddelta), dA.to(A.dtype), dBm, dCm,
+                dD.to(D.dtype) if ctx.has_D else None, cm(dz) if ctx.has_z else None,
+                dbias.to(delta_bias.dtype) if ctx.has_bias else None, None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """Drop-in for mamba_ssm's selective_scan_fn (imported at block/mamba.py:11).
+
+    u, delta, z: (B, D, L); A: (D, N) real; B, C: (B, N, L) or (B, G, N, L) (input-dependent);
+    D, delta_bias: (D,) fp32.  Returns out (B, D, L) [, last_state (B, D, N)].
+    """
+    if A.is_complex():
+        raise NotImplementedError("complex A is not supported (DiffMa uses the real S4D-real init, block/mamba.py:304-310)")
+    if B.dim() not in (3, 4) or C.dim() not in (3, 4):
+        raise NotImplementedError("only input-dependent B/C are supported (the only mode DiffMa uses)")
+    return _SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+class _CausalConv1dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, silu):
+        xt = _to_token_major(x)
+        out = hip_ops.gather_conv1d_fwd(xt, weight, bias, silu=silu)
+        ctx.silu = silu
+        ctx.save_for_backward(xt, weight, bias)
+        return out.transpose(1, 2)
+
+    @staticmethod
+    def backward(ctx, dout):
+        xt, weight, bias = ctx.saved_tensors
+        dot = _to_token_major(dout)
+        if dot.dtype != xt.dtype:
+            dot = dot.to(xt.dtype)
+        dx, dw, db = hip_ops.gather_conv1d_bwd(xt, weight, bias, dot, silu=ctx.silu)
+        return dx.transpose(1, 2), dw.to(weight.dtype).reshape(weight.shape), (db.to(bias.dtype) if bias is not None else None), None
+
+
+def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None, return_final_states=False,
+                     final_states_out=None, activation=None):
+    """Drop-in for causal_conv1d.causal_conv1d_fn (imported at block/mamba.py:13).  x: (B, D, L), weight (D, W)."""
+    if activation not in (None, "silu", "swish"):
+        raise NotImplementedError("activation must be None, silu or swish")
+    if seq_idx is not None or initial_states is not None or return_final_states or final_states_out is not None:
+        raise NotImplementedError("seq_idx / initial_states / final_states are decode-time features DiffMa never uses")
+    return _CausalConv1dFn.apply(x, weight, bias, activation is not None)
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused 3-direction operator of the DiffMa mixer
+# ------------------------------------------------------------------------------------------------
+class _SpiralSSMFn(torch.autograd.Function):
+    """xz [B, L, 2*Din] token-major -> merged pre-projection output y [B, L, Din].
+
+    scan_index [ndir, L]: position l of direction k reads token scan_index[k][l]   (CrossScan, block/mamba.py:41-45)
+    Because CrossMerge adds direction k's output row origina_k[t] at token t and origina_k is the inverse
+    permutation of scan_index[k] (tools.py:38-42), step l's result belongs to token scan_index[k][l]: the
+    same table drives the gather of x and z and the scatter of y.
+    """
+
+    @staticmethod
+    def forward(ctx, xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index):
+        Bsz, L, D2 = xz.shape
+        Din = D2 // 2
+        ndir = scan_index.shape[0]
+        R = Wdt.shape[1]
+        N = A.shape[1]
+        dt_ = xz.dtype
+        x_view, z_view = xz[..., :Din], xz[..., Din:]
+        need_grad = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8])
+        xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
+        x_dbl = F.linear(xc.view(-1, Din), Wx.to(dt_))                         # [ndir*B*L, R+2N]
+        delta = F.linear(x_dbl[:, :R], Wdt.to(dt_)).view(ndir * Bsz, L, Din)
+        xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
+        Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
+        ckpt = None
+        if need_grad:
+            ckpt = torch.empty((ndir * Bsz, hip_ops.scan_nchunk(L), N, Din), dtype=torch.float32, device=xz.device)
+        ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
+                                out_row_index=scan_index, batch_per_dir=Bsz, ckpt=ckpt)             # token order
+        y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din))
+        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt = ctx.saved_tensors
+        Bsz, L, D2 = xz.shape
+        Din = D2 // 2
+        ndir = scan_index.shape[0]
+        R = Wdt.shape[1]
+        N = A.shape[1]
+        dt_ = xz.dtype
+        dy = dy.contiguous()
+        if dy.dtype != dt_:
+            dy = dy.to(dt_)
+        xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
+        Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
+        z_view = xz[..., Din:]
+        du, ddelta, dz, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(
+            xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
+            out_row_index=scan_index, batch_per_dir=Bsz)
+        M = ndir * Bsz * L
+        ddelta2 = ddelta.view(M, Din)
+        dx_dbl = torch.empty((M, R + 2 * N), dtype=dt_, device=xz.device)
+        dx_dbl[:, :R] = ddelta2 @ Wdt.to(dt_)
+        dx_dbl[:, R:R + N].copy_(dB.reshape(M, N))
+        dx_dbl[:, R + N:].copy_(dC.reshape(M, N))
+        dWdt = (ddelta2.t() @ x_dbl[:, :R]).to(Wdt.dtype)                       # [Din, R]
+        dWx = (dx_dbl.t() @ xc.view(M, Din)).to(Wx.dtype)                        # [R+2N, Din]
+        dxc = torch.addmm(du.view(M, Din), dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)
+        dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
+                                                               row_index=scan_index, ndir=ndir, silu=True)
+        dxz = torch.empty_like(xz)
+        hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
+        hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
+        return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
+                dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None)
+
+
+def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, scan_index):
+    """Fused CrossScan -> 3x(conv1d+SiLU, x_proj, dt_proj, selective scan) -> CrossMerge (pre out_proj).
+
+    xz: [B, L, 2*Din] token-major (the in_proj output); A: [Din, N] fp32 (= -exp(A_log));
+    scan_index: int32 [ndir, L] device tensor.  Returns y [B, L, Din]; the caller applies out_proj.
+    """
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _SpiralSSMFn.apply(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b.float(), A.float(), Dskip.float(),
+                                  scan_index)
+
+
+def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
+                   out_proj_bias, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
+                   C_proj_bias=None, delta_softplus=True):
+    """Drop-in for mamba_ssm's mamba_inner_fn with the positional usage of block/mamba.py:346.
+
+    xz: (B, 2*Din, L) (any strides; CrossScan hands out strided slices).  Returns (B, L, d_model).
+    """
+    if B is not None or C is not None or B_proj_bias is not None or C_proj_bias is not None:
+        raise NotImplementedError("constant B/C and B/C projection biases are never used by DiffMa")
+    if not delta_softplus:
+        raise NotImplementedError("mamba_inner_fn is only defined with delta_softplus=True upstream")
+    xzt = _to_token_major(xz)                                                    # [B, L, 2Din]
+    ident = torch.arange(xzt.shape[1], device=xz.device, dtype=torch.int32)[None]
+    bias = delta_bias if delta_bias is not None else torch.zeros(xzt.shape[2] // 2, device=xz.device)
+    Dsk = D if D is not None else torch.zeros(xzt.shape[2] // 2, device=xz.device)
+    y = spiral_ssm(xzt, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, bias, A, Dsk, ident)
+    return F.linear(y, out_proj_weight.to(y.dtype), out_proj_bias)
