@@ -1,0 +1,219 @@
+"""bench.py -- DiffMa-L/2 @224x224 (4x28x28 latents, 196 tokens) data-parallel TRAINING step on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is the reference's training step (train.py:243-265): t ~ U{0..999}, q_sample, denoiser forward,
+loss = mse + vb, backward (RCCL gradient all-reduce through DDP when N > 1), AdamW, EMA update -- on a
+synthetic batch of BASELINE.md section 4 (no datasets / encoders exist offline).  Per-GPU batch is fixed, so
+scaling is weak; `value` = samples*steps per second summed over all ranks ("diffusion-steps/sec").
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  roofline     : the dominant C-ABI kernel of the timed region, timed with events on the launch stream
+  kernels      : the same numbers for every C-ABI kernel
+  cpu_baseline : the oracle port of the same training step on the host cores (rank 0, N = 1 only)
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="DiffMa-L/2")
+    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="train", choices=["train", "sample"])
+    ap.add_argument("--cpu-steps", type=int, default=2, help="training steps of the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--global-seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def rerandomize_zero_init(model, gen_seed):
+    """reference init, then the zero-initialised tensors get N(0, 0.02^2) so that the
+    network is not the identity."""
+    g = torch.Generator().manual_seed(gen_seed)
+    with torch.no_grad():
+        for p in model.parameters():
+            if p.requires_grad and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+
+
+def synthetic_batch(B, tokens, dev, gen):
+    mk = lambda *s: torch.randn(*s, generator=gen, device=dev)
+    return dict(z=mk(B, 4, 28, 28), y=mk(B, 512), y2=mk(B, tokens, 512), w=torch.sigmoid(mk(B, tokens, 1)))
+
+
+@torch.no_grad()
+def update_ema(ema, model, decay=0.999):
+    ep = list(ema.parameters())
+    mp = list(model.parameters())
+    torch._foreach_mul_(ep, decay)
+    torch._foreach_add_(ep, mp, alpha=1 - decay)
+
+
+def cpu_baseline(args, tokens):
+    """The oracle ("port") run of the same training step on the host: batch 1, fp32, all cores."""
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa_models
+    from oracle.model_ref import diffma_forward_ref
+
+    torch.manual_seed(0)
+    net = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
+    rerandomize_zero_init(net, 1)
+    sd = {k: v.detach().clone().requires_grad_(k != "pos_embed") for k, v in net.state_dict().items()}
+    params = [v for k, v in sd.items() if k != "pos_embed"]
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0)
+    d = create_diffusion("")
+    gen = torch.Generator().manual_seed(0)
+    b = synthetic_batch(1, tokens, "cpu", gen)
+    depth, patch = net.depth, net.patch_size
+    model = lambda x, t, **kw: diffma_forward_ref(sd, x, t, kw["y"], kw["y2"], kw["w"], patch_size=patch, depth=depth, dtype=torch.float32)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        t = torch.randint(0, d.num_timesteps, (1,))
+        loss = d.training_losses(model, b["z"], t, dict(y=b["y"], y2=b["y2"], w=b["w"]))["loss"].mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    dt = time.perf_counter() - t0
+    return {"value": args.cpu_steps * 1 / dt, "unit": "samples*steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.cpu_steps} training steps (fwd+bwd+AdamW) of {args.model} at batch 1, fp32, pure-PyTorch oracle "
+                      f"(sequential scan), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    import torch.distributed as dist
+
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+
+    from diffma_amd import _lib, hip_ops
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa_models
+
+    _lib.load()                                                  # fail loudly if the HIP library is missing
+    torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
+    model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
+    rerandomize_zero_init(model, 1)
+    model = model.to(dev)
+    tokens = model.x_embedder.num_patches
+    diffusion = create_diffusion("")
+    B = args.batch_per_gpu
+    gen = torch.Generator(device=dev).manual_seed(args.global_seed * world + rank)
+    batch = synthetic_batch(B, tokens, dev, gen)
+    kw = dict(y=batch["y"], y2=batch["y2"], w=batch["w"])
+    amp = torch.bfloat16 if args.dtype == "bf16" else None
+
+    if args.mode == "train":
+        ema = copy.deepcopy(model).requires_grad_(False)
+        net = model
+        if world > 1:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True)
+        net.train()
+
+        def step():
+            t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
+            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                loss = diffusion.training_losses(net, batch["z"], t, kw)["loss"].mean()
+            loss.backward()
+            opt.step()
+            update_ema(ema, model)
+            opt.zero_grad(set_to_none=True)
+            return loss
+    else:
+        model.eval()
+        sdiff = create_diffusion("250")
+        state = {"x": batch["z"].clone(), "i": sdiff.num_timesteps - 1}
+
+        def step():
+            t = torch.full((B,), state["i"], device=dev, dtype=torch.long)
+            with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                out = sdiff.p_sample(model.forward, state["x"], t, clip_denoised=False, model_kwargs=kw)
+            state["x"] = out["sample"].float()
+            state["i"] = state["i"] - 1 if state["i"] > 0 else sdiff.num_timesteps - 1
+            return out["sample"]
+
+    for _ in range(args.warmup):
+        step()
+    timer = hip_ops.KernelTimer()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    hip_ops.set_timer(timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    hip_ops.set_timer(None)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(last.detach().float()).all(), "non-finite loss/sample in the timed region"
+
+    if rank == 0:
+        ksum = timer.summary()
+        kernels = {}
+        for name, r in ksum.items():
+            gbps = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+            kernels[name] = dict(launches_per_step=r["launches"] / args.steps, avg_us=round(r["avg_us"], 2),
+                                 ms_per_step=round(r["total_ms"] / args.steps, 3), algorithmic_MB_per_launch=round(r["bytes_per_launch"] / 1e6, 3),
+                                 GBps=round(gbps, 1), frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
+        dom = max(ksum, key=lambda n: ksum[n]["total_ms"])
+        r = ksum[dom]
+        achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+        res = {
+            "metric": f"diffusion-steps/sec ({args.model}, 224x224, {'training' if args.mode == 'train' else '250-step DDPM sampling'}; samples*steps/s)",
+            "value": round(args.steps * B * world / elapsed, 3),
+            "unit": "samples*steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
+            "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
+            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" if args.mode == "train"
+                       else f"{args.model} p_sample step, batch {B}/GPU",
+                       "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
+                       "optimizer_steps_per_sec": round(args.steps / elapsed, 4)},
+            "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"])},
+            "kernels": kernels,
+        }
+        if world == 1 and args.cpu_steps > 0 and args.mode == "train":
+            res["cpu_baseline"] = cpu_baseline(args, tokens)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

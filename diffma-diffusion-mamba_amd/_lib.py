@@ -109,7 +109,7 @@ def load():
             fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
             if args in ("void", ""):
                 fn.argtypes = []
-            elif name == "dm_conv_nchunk":
+            elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):
                 fn.argtypes = [ctypes.c_int]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -16,6 +16,50 @@ _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 8    # steps between saved states in training mode (= BWD_CK of scan_bwd.hip)
 
 
+class KernelTimer:
+    """Optional live timing of the C-ABI launches with events recorded on the launch stream (the torch
+    current stream).  bench.py installs one around its timed region; no host sync until `summary()`."""
+
+    def __init__(self):
+        self.records = {}      # name -> list of (start_event, end_event, algorithmic_bytes)
+
+    def launch(self, name, nbytes, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.records.setdefault(name, []).append((e0, e1, nbytes))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            nb = [n for _, _, n in recs]
+            out[name] = dict(launches=len(recs), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
+                             bytes_per_launch=sum(nb) / len(nb))
+        return out
+
+
+_TIMER = None
+
+
+def set_timer(timer):
+    """Install (or remove with None) a KernelTimer; returns the previous one."""
+    global _TIMER
+    prev, _TIMER = _TIMER, timer
+    return prev
+
+
+def _launch(name, args, tensor, nbytes):
+    with torch.cuda.device(tensor.device):
+        if _TIMER is None:
+            _lib.call(name, args, _stream(tensor))
+        else:
+            _TIMER.launch(name, nbytes, lambda: _lib.call(name, args, _stream(tensor)))
+
+
 def dtype_code(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
@@ -83,8 +127,11 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.B_ss, a.B_sl, a.B_sn = Bm.stride()
     a.C_ss, a.C_sl, a.C_sn = Cm.stride()
     a.B_sg = a.C_sg = N
-    with torch.cuda.device(u.device):
-        _lib.call("dm_selective_scan_fwd", a, _stream(u))
+    es = u.element_size()
+    nbytes = 4 * S * Dm * L * es - (0 if z is not None else S * Dm * L * es) + 2 * S * N * L * Bm.element_size() + 4 * Dm * N + 8 * Dm
+    if ckpt is not None:
+        nbytes += (scan_nchunk(L, ckpt_every) - 1) * S * N * Dm * 4
+    _launch("dm_selective_scan_fwd", a, u, nbytes)
     return out
 
 
@@ -97,7 +144,10 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     _require_gpu(u, delta, A, Bm, Cm, z, dout, ckpt)
     S, L, Dm = u.shape
     N = A.shape[1]
-    nw = (Dm + 63) // 64
+    gc = _lib.load().dm_scan_bwd_group_channels(N)
+    if gc <= 0:
+        raise _lib.DiffmaHipError(f"selective-scan backward is not built for d_state={N}")
+    nw = (Dm + gc - 1) // gc
     dev = u.device
     A32, D32, b32 = _f32c(A), _f32c(D), _f32c(delta_bias)
     du = torch.empty_like(u)
@@ -135,8 +185,10 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.B_sg = a.C_sg = N
     a.du_ss, a.du_sl, a.du_sd = du.stride()
     a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
-    with torch.cuda.device(dev):
-        _lib.call("dm_selective_scan_bwd", a, _stream(u))
+    es = u.element_size()
+    nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
+        + (scan_nchunk(L, ckpt_every) - 1) * S * N * Dm * 4
+    _launch("dm_selective_scan_bwd", a, u, nbytes)
     dBCs = dBC.sum(dim=2)                       # [S, L, 2N] fp32, deterministic
     dB, dC = dBCs[..., :N], dBCs[..., N:]
     return (du, ddelta, dz, dB, dC, dA.sum(0), dD.sum(0) if dD is not None else None,
@@ -162,8 +214,7 @@ def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out
     a.x, a.weight, a.bias, a.row_index, a.out = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index), _ptr(out)
     a.x_sb, a.x_sl, a.x_sd = x.stride()
     a.o_ss, a.o_sl, a.o_sd = out.stride()
-    with torch.cuda.device(x.device):
-        _lib.call("dm_gather_conv1d_fwd", a, _stream(x))
+    _launch("dm_gather_conv1d_fwd", a, x, 2 * ndir * Bsz * L * Dm * x.element_size())
     return out
 
 
@@ -194,8 +245,7 @@ def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=Tru
     a.x_sb, a.x_sl, a.x_sd = x.stride()
     a.do_ss, a.do_sl, a.do_sd = dout.stride()
     a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
-    with torch.cuda.device(dev):
-        _lib.call("dm_gather_conv1d_bwd", a, _stream(x))
+    _launch("dm_gather_conv1d_bwd", a, x, 3 * ndir * Bsz * L * Dm * x.element_size())
     return dx, dw.sum(dim=(0, 1)), db.sum(dim=(0, 1))
 
 
@@ -214,6 +264,5 @@ def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
     setattr(a, "in", _ptr(slabs))
     a.in_sk, a.in_sb, a.in_sl = slabs.stride()[:3]
     a.o_sb, a.o_sl = out.stride()[:2]
-    with torch.cuda.device(slabs.device):
-        _lib.call("dm_token_merge", a, _stream(slabs))
+    _launch("dm_token_merge", a, slabs, (K * slabs.element_size() + out.element_size()) * Bsz * L * Dm)
     return out

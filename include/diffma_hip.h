@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 3
+#define DM_ABI_VERSION 4
 
 typedef enum {
     DM_OK = 0,
@@ -103,7 +103,8 @@ int dm_selective_scan_fwd(const dm_scan_fwd_args *args, void *stream);
  *
  *   dout is read at row out_row_index[dir][l] (the gather that is the adjoint of the forward's scatter),
  *   dz is written at row z_row_index[dir][l] of a per-direction buffer [s][row][d].
- *   dB/dC: per-wave partial sums over 64 channels, fp32, layout [s][l][dim/64][2*dstate] (B then C);
+ *   dB/dC: partial sums over groups of GC = dm_scan_bwd_group_channels(dstate) channels, fp32, layout
+ *          [s][l][ceil(dim/GC)][2*dstate] (B then C);
  *   dA: [s][dim][dstate], dD: [s][dim], ddelta_bias: [s][dim]  fp32 per-sequence partials.
  *   The caller reduces the partials (deterministic; no atomics).
  * ---------------------------------------------------------------------------------------------- */
@@ -122,7 +123,7 @@ typedef struct {
     const int32_t *out_row_index;
     const float *ckpt;       /* required */
     void *du, *ddelta, *dz;  /* dz NULL iff z NULL; same dtype as u */
-    float *dBC_partial;      /* [nseq][seqlen][dim/64][2*dstate] */
+    float *dBC_partial;      /* [nseq][seqlen][ceil(dim/GC)][2*dstate] */
     float *dA_partial;       /* [nseq][dim][dstate]              */
     float *dD_partial;       /* [nseq][dim] or NULL              */
     float *dbias_partial;    /* [nseq][dim] or NULL              */
@@ -138,6 +139,7 @@ typedef struct {
 } dm_scan_bwd_args;
 
 int dm_selective_scan_bwd(const dm_scan_bwd_args *args, void *stream);
+int dm_scan_bwd_group_channels(int dstate);   /* GC above; <= 0 if dstate is not instantiated */
 
 /* ------------------------------------------------------------------------------------------------
  * Token gather + causal depthwise conv1d (+bias, +SiLU), forward.  Replaces
