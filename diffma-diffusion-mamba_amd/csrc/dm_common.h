@@ -55,6 +55,75 @@ template <> struct cio<bf16_t> {
 };
 template <> struct cio<f16_t> { static __device__ __forceinline__ float ld(cptr<f16_t> p) { return (float)p->v; } };
 
+// ---- buffer (SRD) addressing ---------------------------------------------------------------------
+// address = base(SGPRx4) + voffset(VGPR, bytes) + soffset(SGPR, bytes): the per-lane part (channel * size)
+// is ONE register shared by every tensor, and the wave-uniform row offset rides in an SGPR, so a row
+// access costs one s_add/s_mul -- no 64-bit scalar multiply, no v_lshl_add_u64 per access.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, /*num_records*/ -1, 0x00020000);
+}
+template <typename T> struct bio;
+template <> struct bio<float> {
+    static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+    }
+};
+template <> struct bio<bf16_t> {
+    static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
+        return __uint_as_float(((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)) << 16);
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
+        bf16_t t;
+        io<bf16_t>::st(&t, x);
+        __builtin_amdgcn_raw_buffer_store_b16(t.v, r, voff, soff, 0);
+    }
+};
+template <> struct bio<f16_t> {
+    static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
+        const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+        _Float16 h;
+        __builtin_memcpy(&h, &b, 2);
+        return (float)h;
+    }
+    static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
+        const _Float16 h = (_Float16)x;
+        unsigned short b;
+        __builtin_memcpy(&b, &h, 2);
+        __builtin_amdgcn_raw_buffer_store_b16(b, r, voff, soff, 0);
+    }
+};
+// NS consecutive elements (NS*sizeof(T) in {4, 8, 16} bytes use one wide load)
+template <typename T, int NS>
+__device__ __forceinline__ void bio_ld_vec(float (&v)[NS], rsrc_t r, int voff, int soff) {
+    constexpr int BYTES = NS * (int)sizeof(T);
+    if constexpr (BYTES == 16) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        alignas(16) uint32_t w[4] = {q[0], q[1], q[2], q[3]};
+        const T* e = reinterpret_cast<const T*>(w);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = io<T>::ld(e + k);
+    } else if constexpr (BYTES == 8) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        alignas(8) uint32_t w[2] = {q[0], q[1]};
+        const T* e = reinterpret_cast<const T*>(w);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = io<T>::ld(e + k);
+    } else if constexpr (BYTES == 32) {
+        float lo[NS / 2], hi[NS / 2];
+        bio_ld_vec<T, NS / 2>(lo, r, voff, soff);
+        bio_ld_vec<T, NS / 2>(hi, r, voff + 16, soff);
+#pragma unroll
+        for (int k = 0; k < NS / 2; ++k) { v[k] = lo[k]; v[NS / 2 + k] = hi[k]; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = bio<T>::ld(r, voff + k * (int)sizeof(T), soff);
+    }
+}
+
 // ---- transcendental helpers (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp, no range fix-ups) ----
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }

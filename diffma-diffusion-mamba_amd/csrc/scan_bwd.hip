@@ -73,28 +73,26 @@ __device__ __forceinline__ void channel_reduce(float (&v)[M]) {
     }
 }
 
-// NS consecutive elements starting at p (4-byte aligned is enough), converted to fp32
-template <typename TBC, int NS>
-__device__ __forceinline__ void load_slice(float (&v)[NS], const TBC* p) {
-    struct __attribute__((packed, aligned(4))) raw_t { TBC e[NS]; };
-    struct __attribute__((packed, aligned(2))) raw2_t { TBC e[NS]; };
-    if (sizeof(TBC) * NS % 4 == 0) {
-        const raw_t r = *reinterpret_cast<const raw_t*>(p);
-#pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = io<TBC>::ld(&r.e[k]);
-    } else {
-        const raw2_t r = *reinterpret_cast<const raw2_t*>(p);
-#pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = io<TBC>::ld(&r.e[k]);
-    }
+// make a value opaque to the optimiser (costs no instruction): stops it from keeping the exp() / B-row
+// values of the recompute pass alive across the whole chunk just to save recomputing them
+__device__ __forceinline__ float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ int opaque_i(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 
 template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS>
 __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_bwd_args p) {
-    constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, M = 2 * NS, R = M / 4;
+    constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = 4, M = 2 * NS, R = M / 4;
+    constexpr int ES = (int)sizeof(T);
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
-    static_assert(R <= 16 / SPLIT, "not enough writer lanes per row");
+    static_assert(R <= 16 / SPLIT, "not enough stager lanes per row");
+    static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     __shared__ float red_lds[2][BWD_WAVES][CK][2 * N];
+    __shared__ __attribute__((aligned(16))) float bc_lds[2][CK][2 * N];   // [B row | C row] of every step of a chunk, all waves share a sequence
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -104,24 +102,29 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
     const int d = active ? d_raw : p.dim - 1;
     const int s = blockIdx.y;
     const int L = p.seqlen;
-    const int i_u_sl = (int)p.u_sl, i_dt_sl = (int)p.dt_sl, i_z_sl = (int)p.z_sl, i_do_sl = (int)p.do_sl;
-    const int i_du_sl = (int)p.du_sl, i_ddt_sl = (int)p.ddt_sl, i_dz_sl = (int)p.dz_sl;
-    const int i_B_sl = (int)p.B_sl, i_C_sl = (int)p.C_sl;
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
     const int grp = (blockIdx.x * BWD_WAVES * CW) / (p.dim / p.ngroups);
     const int nwg = gridDim.x;
+    const int nchunk = (L + CK - 1) / CK;
 
-    const T* __restrict__ up = (const T*)p.u + (int64_t)s * p.u_ss + d;
-    const T* __restrict__ dp = (const T*)p.delta + (int64_t)s * p.dt_ss + d;
-    const T* __restrict__ zp = HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss + d : nullptr;
-    const T* __restrict__ gp = (const T*)p.dout + (int64_t)(IDX ? sb : s) * p.do_ss + d;
-    T* __restrict__ dup = (T*)p.du + (int64_t)s * p.du_ss + d;
-    T* __restrict__ ddp = (T*)p.ddelta + (int64_t)s * p.ddt_ss + d;
-    T* __restrict__ dzp = HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss + d : nullptr;
-    const TBC* __restrict__ Bp = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg + q * NS;
-    const TBC* __restrict__ Cp = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg + q * NS;
+    // one SRD per tensor, based at this sequence; row offsets are wave-uniform byte offsets in SGPRs
+    const rsrc_t r_u = make_rsrc((const T*)p.u + (int64_t)s * p.u_ss);
+    const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
+    const rsrc_t r_g = make_rsrc((const T*)p.dout + (int64_t)(IDX ? sb : s) * p.do_ss);
+    const rsrc_t r_du = make_rsrc((T*)p.du + (int64_t)s * p.du_ss);
+    const rsrc_t r_ddt = make_rsrc((T*)p.ddelta + (int64_t)s * p.ddt_ss);
+    const rsrc_t r_dz = make_rsrc(HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);
+    const TBC* __restrict__ Bg = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
+    const TBC* __restrict__ Cg = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
+    const rsrc_t r_ck = make_rsrc(p.ckpt ? p.ckpt + (int64_t)s * nchunk * N * p.dim : nullptr);
+    const int vo = d * ES;                 // per-lane byte offset of the channel, shared by all T tensors
+    const int vo_ck = d * 4;
+    const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_g = (int)p.do_sl * ES;
+    const int sl_du = (int)p.du_sl * ES, sl_ddt = (int)p.ddt_sl * ES, sl_dz = (int)p.dz_sl * ES;
+    const int i_B_sl = (int)p.B_sl, i_C_sl = (int)p.C_sl;
     const cptr<int32_t> zidx = IDX ? as_const(p.z_row_index + (int64_t)dir * L) : nullptr;
     const cptr<int32_t> oidx = IDX ? as_const(p.out_row_index + (int64_t)dir * L) : nullptr;
 
@@ -139,64 +142,90 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
     for (int k = 0; k < NPL; ++k) { carry[k] = (f32x2){0.f, 0.f}; dA[k] = (f32x2){0.f, 0.f}; }
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    const int nchunk = (L + CK - 1) / CK;
     // which reduced register this lane stages in LDS, and where
     const int jrow = (lane & 15) / SPLIT;                         // index of the lane among its row's same-q lanes
     const int vidx = 4 * jrow + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);      // value index in [0, M) if jrow < R
     const int col = (vidx < NS) ? (q * NS + vidx) : (N + q * NS + vidx - NS);   // [dB(0..N) | dC(0..N)]
     const bool stager = jrow < R;
 
+    // B/C rows of a chunk: CK*2N values, fetched cooperatively (one or two per thread), one chunk ahead
+    constexpr int BC_PER_THREAD = (CK * 2 * N + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);
+    auto fetch_bc = [&](int chunk, float(&v)[BC_PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < BC_PER_THREAD; ++i) {
+            const int e = tid + i * 64 * BWD_WAVES;
+            const int j = e / (2 * N), cc = e % (2 * N);
+            int l = chunk * CK + j;
+            l = (l < L) ? l : L - 1;
+            v[i] = 0.f;
+            if (e < CK * 2 * N) v[i] = (cc < N) ? io<TBC>::ld(Bg + l * i_B_sl + cc) : io<TBC>::ld(Cg + l * i_C_sl + cc - N);
+        }
+    };
+    auto stash_bc = [&](int b, const float(&v)[BC_PER_THREAD]) {
+#pragma unroll
+        for (int i = 0; i < BC_PER_THREAD; ++i) {
+            const int e = tid + i * 64 * BWD_WAVES;
+            if (e < CK * 2 * N) bc_lds[b][e / (2 * N)][e % (2 * N)] = v[i];
+        }
+    };
+    {
+        float v[BC_PER_THREAD];
+        fetch_bc(nchunk - 1, v);
+        stash_bc(0, v);
+    }
+    __syncthreads();
+
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int l0 = ch * CK;
+        float bc_next[BC_PER_THREAD];
+        if (ch > 0) fetch_bc(ch - 1, bc_next);          // lands while this chunk computes
         // ---- chunk inputs (invalid tail steps become exact no-ops: dl = u = g = 0) -------------------
         float uu[CK], dl[CK], zz[CK], gg[CK];
-        {
-            T ru[CK], rd[CK], rz[CK], rg[CK];
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const int l = (l0 + j < L) ? l0 + j : L - 1;
-                ru[j] = up[l * i_u_sl];
-                rd[j] = dp[l * i_dt_sl];
-                if (HAS_Z) rz[j] = zp[(IDX ? zidx[l] : l) * i_z_sl];
-                rg[j] = gp[(IDX ? oidx[l] : l) * i_do_sl];
-            }
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const bool valid = (l0 + j) < L;
-                uu[j] = valid ? io<T>::ld(&ru[j]) : 0.f;
-                float x = io<T>::ld(&rd[j]) + bias;
-                if (SOFTPLUS) x = softplus_f(x);
-                dl[j] = valid ? x : 0.f;
-                zz[j] = HAS_Z ? io<T>::ld(&rz[j]) : 0.f;
-                gg[j] = (valid && active) ? io<T>::ld(&rg[j]) : 0.f;
-            }
-        }
-        // ---- state slice entering the chunk ---------------------------------------------------------
-        f32x2 h[NPL];
-        if (ch == 0) {
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) h[k] = (f32x2){0.f, 0.f};
-        } else {
-            const float* ck = p.ckpt + (((int64_t)s * nchunk + ch) * N + q * NS) * p.dim + d;
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                h[k].x = ck[(int64_t)(2 * k) * p.dim];
-                h[k].y = ck[(int64_t)(2 * k + 1) * p.dim];
-            }
-        }
-        // ---- forward recompute: hs[j] = state before step j ---------------------------------------------
-        f32x2 hs[CK][NPL];
+        int zrow[CK];
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
             const int l = (l0 + j < L) ? l0 + j : L - 1;
-            float Bv[NS];
-            load_slice<TBC, NS>(Bv, Bp + l * i_B_sl);
-            const float du = dl[j] * uu[j];
+            zrow[j] = IDX ? zidx[l] : l;
+            const int orow = IDX ? oidx[l] : l;
+            uu[j] = bio<T>::ld(r_u, vo, l * sl_u);
+            dl[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
+            zz[j] = HAS_Z ? bio<T>::ld(r_z, vo, zrow[j] * sl_z) : 0.f;
+            gg[j] = bio<T>::ld(r_g, vo, orow * sl_g);
+        }
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const bool valid = (l0 + j) < L;
+            float x = dl[j] + bias;
+            if (SOFTPLUS) x = softplus_f(x);
+            dl[j] = valid ? x : 0.f;
+            uu[j] = valid ? uu[j] : 0.f;
+            gg[j] = (valid && active) ? gg[j] : 0.f;
+        }
+        // ---- state slice entering the chunk ---------------------------------------------------------
+        f32x2 h0[NPL];
+        if (ch == 0) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) h0[k] = (f32x2){0.f, 0.f};
+        } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                hs[j][k] = h[k];
-                const f32x2 t = A2[k] * dl[j];
+                h0[k].x = bio<float>::ld(r_ck, vo_ck, ((ch * N + q * NS + 2 * k) * p.dim) * 4);
+                h0[k].y = bio<float>::ld(r_ck, vo_ck, ((ch * N + q * NS + 2 * k + 1) * p.dim) * 4);
+            }
+        }
+
+        // one forward step of the slice: h <- a*h + B*dl*u   (used by all three recompute passes)
+        auto fwd_step = [&](f32x2(&h)[NPL], int j) {
+            float Bv[NS];
+            const float* brow = &bc_lds[0][0][0] + opaque_i((buf * CK + j) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Bv[k] = brow[k];
+            const float dlo = opaque(dl[j]);
+            const float du = dlo * uu[j];
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const f32x2 t = A2[k] * dlo;
                 f32x2 a;
                 a.x = fast_exp2(t.x);
                 a.y = fast_exp2(t.y);
@@ -205,78 +234,100 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                 bb.y = Bv[2 * k + 1];
                 h[k] = a * h[k] + bb * du;
             }
-            __builtin_amdgcn_sched_barrier(0);   // bound live ranges: one step's operands at a time
-        }
-        // ---- reverse sweep (h = state AFTER step j at the top of iteration j) ---------------------------
+        };
+
+        // Two-level recompute: sub-chunks of SUB steps, last one first.  The states of ONE sub-chunk live
+        // in registers (hs); earlier sub-chunks are re-advanced from the chunk's entry state when needed.
 #pragma unroll
-        for (int j = CK - 1; j >= 0; --j) {
-            const int lraw = l0 + j;
-            const bool valid = lraw < L;                    // wave-uniform
-            const int l = valid ? lraw : L - 1;
-            float Bv[NS], Cv[NS];
-            load_slice<TBC, NS>(Bv, Bp + l * i_B_sl);
-            load_slice<TBC, NS>(Cv, Cp + l * i_C_sl);
-            const float g = gg[j];
-            float sz = 1.f, gy = g;
-            if (HAS_Z) {
-                sz = sigmoid_f(zz[j]);
-                gy = g * zz[j] * sz;
-            }
-            const float du = dl[j] * uu[j];
-            f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
-            float red[M];
+        for (int sc = CK / SUB - 1; sc >= 0; --sc) {
+            f32x2 h[NPL];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                f32x2 bb, cc;
-                bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
-                cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
-                const f32x2 t = A2[k] * dl[j];
-                f32x2 a;
-                a.x = fast_exp2(t.x);
-                a.y = fast_exp2(t.y);
-                const f32x2 hj = h[k];
-                const f32x2 hp = hs[j][k];
-                yp2 += cc * hj;
-                const f32x2 G = cc * gy + carry[k];          // dL/dh_j
-                const f32x2 dCp = hj * gy;
-                const f32x2 Gt = G * (a * hp);
-                dlA2 += A2[k] * Gt;
-                dA[k] += Gt * dl[j];
-                GB2 += G * bb;
-                const f32x2 dBp = G * du;
-                carry[k] = a * G;
-                red[2 * k] = dBp.x;
-                red[2 * k + 1] = dBp.y;
-                red[NS + 2 * k] = dCp.x;
-                red[NS + 2 * k + 1] = dCp.y;
-                h[k] = hp;
+            for (int k = 0; k < NPL; ++k) h[k] = h0[k];
+#pragma unroll
+            for (int j = 0; j < sc * SUB; ++j) fwd_step(h, j);           // advance to the sub-chunk start
+            f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) hs[i][k] = h[k];
+                fwd_step(h, sc * SUB + i);
             }
-            const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[j];
-            const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
-            const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
-            float ddl = uu[j] * GB + LN2 * dlA;
-            const float duv = dl[j] * GB + gy * Dv;
-            if (SOFTPLUS) ddl *= (1.0f - fast_exp2(-dl[j] * LOG2E));   // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
-            if (q == 0) {                                               // one lane per channel owns the channel sums
-                dD_acc += gy * uu[j];
-                dbias_acc += ddl;
-            }
-            if (valid && active && q == 0) {
-                io<T>::st(dup + l * i_du_sl, duv);
-                io<T>::st(ddp + l * i_ddt_sl, ddl);
-                if (HAS_Z) {
-                    const float dzv = g * ypre * sz * (1.0f + zz[j] * (1.0f - sz));
-                    io<T>::st(dzp + (IDX ? zidx[l] : l) * i_dz_sl, dzv);
+            // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
+#pragma unroll
+            for (int i = SUB - 1; i >= 0; --i) {
+                const int j = sc * SUB + i;
+                const int lraw = l0 + j;
+                const bool valid = lraw < L;                    // wave-uniform
+                const int l = valid ? lraw : L - 1;
+                float Bv[NS], Cv[NS];
+                const float* brow = &bc_lds[0][0][0] + opaque_i((buf * CK + j) * 2 * N + q * NS);
+#pragma unroll
+                for (int k = 0; k < NS; ++k) {
+                    Bv[k] = brow[k];
+                    Cv[k] = brow[N + k];
                 }
-            }
-            channel_reduce<M, SPLIT>(red);
-            float val = red[0];
+                const float g = gg[j];
+                float sz = 1.f, gy = g;
+                if (HAS_Z) {
+                    sz = sigmoid_f(zz[j]);
+                    gy = g * zz[j] * sz;
+                }
+                const float dlo = opaque(dl[j]);
+                const float du = dlo * uu[j];
+                f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
+                float red[M];
 #pragma unroll
-            for (int r = 1; r < R; ++r) val = (jrow == r) ? red[r] : val;
-            if (stager) red_lds[buf][wave][j][col] = val;
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < NPL; ++k) {
+                    f32x2 bb, cc;
+                    bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
+                    cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
+                    const f32x2 t = A2[k] * dlo;
+                    f32x2 a;
+                    a.x = fast_exp2(t.x);
+                    a.y = fast_exp2(t.y);
+                    const f32x2 hj = h[k];
+                    const f32x2 hp = hs[i][k];
+                    yp2 += cc * hj;
+                    const f32x2 G = cc * gy + carry[k];          // dL/dh_j
+                    const f32x2 dCp = hj * gy;
+                    const f32x2 Gt = G * (a * hp);
+                    dlA2 += A2[k] * Gt;
+                    dA[k] += Gt * dlo;
+                    GB2 += G * bb;
+                    const f32x2 dBp = G * du;
+                    carry[k] = a * G;
+                    red[2 * k] = dBp.x;
+                    red[2 * k + 1] = dBp.y;
+                    red[NS + 2 * k] = dCp.x;
+                    red[NS + 2 * k + 1] = dCp.y;
+                    h[k] = hp;
+                }
+                const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[j];
+                const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
+                const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
+                float ddl = uu[j] * GB + LN2 * dlA;
+                const float duv = dlo * GB + gy * Dv;
+                if (SOFTPLUS) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));   // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+                if (q == 0) {                                             // one lane per channel owns the channel sums
+                    dD_acc += gy * uu[j];
+                    dbias_acc += ddl;
+                }
+                if (valid && active && q == 0) {
+                    bio<T>::st(r_du, vo, l * sl_du, duv);
+                    bio<T>::st(r_ddt, vo, l * sl_ddt, ddl);
+                    if (HAS_Z) {
+                        const float dzv = g * ypre * sz * (1.0f + zz[j] * (1.0f - sz));
+                        bio<T>::st(r_dz, vo, zrow[j] * sl_dz, dzv);
+                    }
+                }
+                channel_reduce<M, SPLIT>(red);
+                float val = red[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) val = (jrow == r) ? red[r] : val;
+                if (stager) red_lds[buf][wave][j][col] = val;
+            }
         }
-        // ---- sum the 4 waves' dB/dC rows of this chunk and store them ------------------------------------
+        // ---- sum the workgroup's waves' dB/dC rows of this chunk and store them --------------------------
         __syncthreads();
         for (int e = tid; e < CK * 2 * N; e += 64 * BWD_WAVES) {
             const int j = e / (2 * N), cc = e % (2 * N);
@@ -287,6 +338,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                 p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
             }
         }
+        if (ch > 0) stash_bc(buf ^ 1, bc_next);
+        __syncthreads();
         buf ^= 1;
     }
     if (active) {
@@ -303,7 +356,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
     }
 }
 
-template <int N> struct bwd_split { static constexpr int value = (N >= 16) ? 4 : (N >= 8 ? 2 : 1); };
+template <int N> struct bwd_split { static constexpr int value = (N >= 16) ? 2 : 1; };   // lanes per channel
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {

@@ -33,12 +33,15 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--L", type=int, default=196)
     ap.add_argument("--D", type=int, default=1024)
+    ap.add_argument("--only", default="", help="comma list of kernels: scan_fwd,scan_bwd,conv,merge,copy")
     args = ap.parse_args()
     dt = {"fp32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
     s = 4 if dt == torch.float32 else 2
     dev = torch.device("cuda", 0)
     L, Dm, N = args.L, args.D, 16
     res = []
+    only = set(filter(None, args.only.split(",")))
+    want = lambda k: not only or k in only
     for S in args.batch:
         u = torch.randn(S, L, Dm, device=dev).to(dt)
         delta = (torch.randn(S, L, Dm, device=dev) * 0.5).to(dt)
@@ -49,12 +52,26 @@ def main():
         Dp = torch.randn(Dm, device=dev)
         bias = torch.randn(Dm, device=dev) * 0.5
         out = torch.empty_like(u)
-        t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out), args.iters)
-        nbytes = 4 * S * Dm * L * s + 2 * S * N * L * s + 4 * Dm * N + 8 * Dm
-        r = dict(kernel="scan_fwd", S=S, dtype=args.dtype, us=t * 1e6, GBps=nbytes / t / 1e9,
-                 frac_8TBps=nbytes / t / 8e12, Gelem_s=S * Dm * L / t / 1e9)
-        print(json.dumps(r), flush=True)
-        res.append(r)
+        if want("scan_fwd"):
+            t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out), args.iters)
+            nbytes = 4 * S * Dm * L * s + 2 * S * N * L * s + 4 * Dm * N + 8 * Dm
+            r = dict(kernel="scan_fwd", S=S, dtype=args.dtype, us=t * 1e6, GBps=nbytes / t / 1e9,
+                     frac_8TBps=nbytes / t / 8e12, Gelem_s=S * Dm * L / t / 1e9)
+            print(json.dumps(r), flush=True)
+            res.append(r)
+        if want("scan_bwd"):
+            K = hip_ops.SCAN_CKPT_EVERY
+            ckpt = torch.empty(S, hip_ops.scan_nchunk(L, K), N, Dm, device=dev)
+            hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out, ckpt=ckpt, ckpt_every=K)
+            t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out, ckpt=ckpt, ckpt_every=K), args.iters)
+            print(json.dumps(dict(kernel="scan_fwd_ckpt", S=S, dtype=args.dtype, us=t * 1e6, Gelem_s=S * Dm * L / t / 1e9)), flush=True)
+            dout = torch.randn(S, L, Dm, device=dev).to(dt)
+            t = timeit(lambda: hip_ops.scan_bwd(u, delta, A, Bm, Cm, Dp, z, bias, dout, ckpt, True, ckpt_every=K), args.iters)
+            nbytes = 7 * S * Dm * L * s + 2 * S * N * L * s
+            print(json.dumps(dict(kernel="scan_bwd(+partial sums)", S=S, dtype=args.dtype, us=t * 1e6, GBps=nbytes / t / 1e9,
+                                  Gelem_s=S * Dm * L / t / 1e9)), flush=True)
+        if not (want("conv") or want("merge") or want("copy")):
+            continue
         # conv (3 directions) : reads x once per direction, writes 3 outputs
         xz = torch.randn(S, L, 2 * Dm, device=dev).to(dt)
         w = torch.randn(Dm, 4, device=dev)
