@@ -18,27 +18,14 @@
 //   * CrossScan's z gather and CrossMerge's inverse reindex are folded into the row addressing
 //     (z_row_index / out_row_index), so the (B,3,2D,L) buffer of block/mamba.py:41 never exists.
 #include "dm_common.h"
+#include <type_traits>
 
 namespace dm {
 
-// Wave-uniform B_l / C_l rows -> SGPRs (scalar cache).  Issued one step ahead of their use.
-template <typename TBC, int N>
-__device__ __forceinline__ void load_bc(float (&Bv)[N], float (&Cv)[N], const TBC* Bp, const TBC* Cp, int bsl,
-                                        int csl, int l) {
-    const cptr<TBC> Bl = as_const(Bp + l * bsl);
-    const cptr<TBC> Cl = as_const(Cp + l * csl);
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        Bv[k] = cio<TBC>::ld(Bl + k);
-        Cv[k] = cio<TBC>::ld(Cl + k);
-    }
-}
-
 // One time step of the recurrence for one lane.
-template <typename T, typename TBC, int N, bool HAS_Z, bool SOFTPLUS>
+template <int N, bool HAS_Z, bool SOFTPLUS>
 __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[N / 2], const float (&Bv)[N],
-                                           const float (&Cv)[N], float uu, float draw, float zz, float Dv,
-                                           float bias) {
+                                           const float (&Cv)[N], float uu, float draw, float zz, float Dv, float bias) {
     float dl = draw + bias;
     if (SOFTPLUS) dl = softplus_f(dl);
     const float du = dl * uu;
@@ -67,30 +54,43 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF>
 __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) {
     static_assert(N % 2 == 0, "d_state must be even");
+    static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
     constexpr int NP = N / 2;
-    const int d = blockIdx.x * WAVE + threadIdx.x;
-    if (d >= p.dim) return;   // no cross-lane traffic anywhere below: idle lanes simply leave
+    constexpr int ES = (int)sizeof(T), EBC = (int)sizeof(TBC);
+    // B_l / C_l rows are shared by every channel of a sequence.  The wave fetches the rows of a whole
+    // block of PF steps with ONE vector load per lane (lane = step*8 + part; N/4 consecutive values each),
+    // parks them in its private 2 x (PF*2N*4 B) LDS slab as fp32, and every step reads its [B | C] row back
+    // with broadcast ds_read_b128.  Nothing here is wave-shared, so no barrier is needed.
+    constexpr int PER = N / 4;                       // B/C values fetched per lane per block
+    __shared__ __attribute__((aligned(16))) float bc_lds[2][PF][2 * N];
+    const int d_raw = blockIdx.x * WAVE + threadIdx.x;
+    // Lanes past the last channel shadow channel dim-1: they help fetching B/C and then compute and store
+    // exactly the same values to exactly the same addresses as that lane (a benign duplicate store), which
+    // keeps every store unpredicated.
+    const int d = (d_raw < p.dim) ? d_raw : p.dim - 1;
     const int s = blockIdx.y;
     const int L = p.seqlen;
-    // in-sequence row offsets fit 32 bits (validated by the host entry point)
-    const int i_B_sl = (int)p.B_sl;
-    const int i_C_sl = (int)p.C_sl;
-    const int i_dt_sl = (int)p.dt_sl;
-    const int i_o_sl = (int)p.o_sl;
-    const int i_u_sl = (int)p.u_sl;
-    const int i_z_sl = (int)p.z_sl;
-
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
     const int grp = (blockIdx.x * WAVE) / (p.dim / p.ngroups);
 
-    const T* __restrict__ up = (const T*)p.u + (int64_t)s * p.u_ss + d;
-    const T* __restrict__ dp = (const T*)p.delta + (int64_t)s * p.dt_ss + d;
-    const T* __restrict__ zp = HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss + d : nullptr;
-    T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss + d;
-    const TBC* Bp = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
-    const TBC* Cp = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
+    // SRD addressing: one descriptor per tensor based at this sequence, the lane's channel offset in ONE
+    // VGPR, wave-uniform row offsets in SGPRs (dm_common.h).
+    const rsrc_t r_u = make_rsrc((const T*)p.u + (int64_t)s * p.u_ss);
+    const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
+    const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
+    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss);
+    const int vo = d * ES;
+    const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_o = (int)p.o_sl * ES;
+    const int lane = threadIdx.x;
+    const int bc_step = lane >> 3, bc_part = lane & 7;                    // part 0..3 -> B, 4..7 -> C
+    const bool bc_isB = bc_part < 4;
+    const rsrc_t r_bc = make_rsrc(bc_isB ? (const void*)((const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg)
+                                         : (const void*)((const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg));
+    const int sl_bc = (int)(bc_isB ? p.B_sl : p.C_sl) * EBC;
+    const int vo_bc = (bc_part & 3) * PER * EBC;
+    float* const bc_slot = &bc_lds[0][bc_step][(bc_isB ? 0 : N) + (bc_part & 3) * PER];   // + buf*PF*2N
     const cptr<int32_t> zidx = IDX ? as_const(p.z_row_index + (int64_t)dir * L) : nullptr;
     const cptr<int32_t> oidx = IDX ? as_const(p.out_row_index + (int64_t)dir * L) : nullptr;
 
@@ -110,61 +110,91 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
 
     const int K = CKPT ? p.ckpt_every : 1;
     const int nchunk = CKPT ? (L + K - 1) / K : 0;
+    const rsrc_t r_ck = make_rsrc(CKPT ? p.ckpt + (int64_t)s * nchunk * N * p.dim : nullptr);
 
     // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
-    T ru[PF], rd[PF], rz[PF];
+    float ru[PF], rd[PF], rz[PF];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         const int l = (j < L) ? j : L - 1;
-        ru[j] = up[l * i_u_sl];
-        rd[j] = dp[l * i_dt_sl];
-        if (HAS_Z) rz[j] = zp[(IDX ? zidx[l] : l) * i_z_sl];
+        ru[j] = bio<T>::ld(r_u, vo, l * sl_u);
+        rd[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
+        if (HAS_Z) rz[j] = bio<T>::ld(r_z, vo, (IDX ? zidx[l] : l) * sl_z);
     }
+    auto fetch_bc = [&](int l0, float(&v)[PER]) {        // rows l0 .. l0+PF-1 (clamped), this lane's piece
+        int l = l0 + bc_step;
+        l = (l < L) ? l : L - 1;
+        // NB r_bc differs between the B-lanes and the C-lanes of the wave: the compiler turns the
+        // non-uniform descriptor into a 2-trip waterfall loop; it runs once per 8 steps.
+        bio_ld_vec<TBC, PER>(v, r_bc, vo_bc, l * sl_bc);
+    };
+    auto stash_bc = [&](int b, const float(&v)[PER]) {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) bc_slot[b * PF * 2 * N + k] = v[k];
+    };
+    {
+        float v[PER];
+        fetch_bc(0, v);
+        stash_bc(0, v);
+    }
+    int buf = 0;
 
-    float Bc[N], Cc[N];
-    load_bc<TBC, N>(Bc, Cc, Bp, Cp, i_B_sl, i_C_sl, 0);
-
-    const int Lfull = (L / PF) * PF;
-    for (int l0 = 0; l0 < Lfull; l0 += PF) {
-        T nu[PF], nd[PF], nz[PF];
+    // One block of PF steps: request the NEXT block's rows into (nu, nd, nz, nbc), then run the PF steps on
+    // the rows that are already here.  The caller alternates two register sets (ping-pong), so the ring
+    // never needs a register-to-register copy.
+    auto run_block = [&](int l0, const float(&cu)[PF], const float(&cd)[PF], const float(&cz)[PF], float(&nu)[PF],
+                         float(&nd)[PF], float(&nz)[PF]) {
+        float nbc[PER];
+        fetch_bc(l0 + PF, nbc);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             int l = l0 + PF + j;
             l = (l < L) ? l : L - 1;
-            nu[j] = up[l * i_u_sl];
-            nd[j] = dp[l * i_dt_sl];
-            if (HAS_Z) nz[j] = zp[(IDX ? zidx[l] : l) * i_z_sl];
+            nu[j] = bio<T>::ld(r_u, vo, l * sl_u);
+            nd[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
+            if (HAS_Z) nz[j] = bio<T>::ld(r_z, vo, (IDX ? zidx[l] : l) * sl_z);
         }
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             const int l = l0 + j;
-            float Bn[N], Cn[N];
-            {
-                const int ln = (l + 1 < L) ? l + 1 : L - 1;
-                load_bc<TBC, N>(Bn, Cn, Bp, Cp, i_B_sl, i_C_sl, ln);
-            }
-            const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
-                                                                  HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
-            io<T>::st(op + (IDX ? oidx[l] : l) * i_o_sl, y);
+            float Bc[N], Cc[N];
 #pragma unroll
-            for (int k = 0; k < N; ++k) { Bc[k] = Bn[k]; Cc[k] = Cn[k]; }
+            for (int k = 0; k < N; ++k) {
+                Bc[k] = bc_lds[buf][j][k];
+                Cc[k] = bc_lds[buf][j][N + k];
+            }
+            const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
+            bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
         }
         if (CKPT) {
             const int done = l0 + PF;                 // steps finished; wave-uniform
             if (done % K == 0 && done < L) {          // state entering chunk done/K
-                float* ck = p.ckpt + (((int64_t)s * nchunk + done / K) * N) * p.dim + d;
+                const int c = done / K;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
-                    ck[(int64_t)(2 * k) * p.dim] = h[k].x;
-                    ck[(int64_t)(2 * k + 1) * p.dim] = h[k].y;
+                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
+                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
                 }
             }
         }
+        buf ^= 1;
+        stash_bc(buf, nbc);
+    };
+
+    const int Lfull = (L / PF) * PF;
+    float su[PF], sd[PF], sz[PF];             // second register set of the ring
+    int l0 = 0;
+    for (; l0 + 2 * PF <= Lfull; l0 += 2 * PF) {
+        run_block(l0, ru, rd, rz, su, sd, sz);
+        run_block(l0 + PF, su, sd, sz, ru, rd, rz);
+    }
+    if (l0 < Lfull) {                          // odd number of full blocks
+        run_block(l0, ru, rd, rz, su, sd, sz);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
-            ru[j] = nu[j];
-            rd[j] = nd[j];
-            if (HAS_Z) rz[j] = nz[j];
+            ru[j] = su[j];
+            rd[j] = sd[j];
+            if (HAS_Z) rz[j] = sz[j];
         }
     }
     // tail (< PF steps); its rows are already in the ring
@@ -172,11 +202,14 @@ __global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) 
     for (int j = 0; j < PF; ++j) {
         const int l = Lfull + j;
         if (l < L) {
-            const float y = scan_step<T, TBC, N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, io<T>::ld(&ru[j]), io<T>::ld(&rd[j]),
-                                                                  HAS_Z ? io<T>::ld(&rz[j]) : 0.0f, Dv, bias);
-            io<T>::st(op + (IDX ? oidx[l] : l) * i_o_sl, y);
-            const int ln = (l + 1 < L) ? l + 1 : L - 1;
-            load_bc<TBC, N>(Bc, Cc, Bp, Cp, i_B_sl, i_C_sl, ln);
+            float Bc[N], Cc[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                Bc[k] = bc_lds[buf][j][k];
+                Cc[k] = bc_lds[buf][j][N + k];
+            }
+            const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
+            bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
         }
     }
 
