@@ -1,0 +1,78 @@
+"""Sharded sampling driver (reference sample.py:29-131): every rank samples its own shard, no collective.
+
+    torchrun --nnodes=1 --nproc_per_node=N sample.py --config config/brain.yaml [--synthetic] [--ddim] [--num-batches K]
+
+`create_diffusion(str(sample_num_steps))` + `p_sample_loop(model.forward, shape, z, clip_denoised=False, ...)` as
+in the reference; `--ddim` switches to `create_diffusion("ddim<steps>")` + `ddim_sample_loop` (the API exists in
+the reference, gaussian_diffusion.py:600, but no script calls it; BASELINE config 5 needs it).  The frozen VAE /
+CLIP / CT encoders need network weights, so offline only `--synthetic` conditioning is possible and the result is
+the sampled LATENT batch (saved as .pt), not decoded PNGs.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+
+import torch
+import torch.distributed as dist
+
+from .config import load_config
+from .diffusion import create_diffusion
+from .model import DiffMa_models
+
+
+def find_model(path, key="ema"):
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    return ckpt[key] if key in ckpt else ckpt
+
+
+def main(args):
+    torch.manual_seed(args.seed)
+    torch.set_grad_enabled(False)
+    if "RANK" in os.environ and not dist.is_initialized():
+        dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    device = torch.device("cuda", rank % torch.cuda.device_count()) if torch.cuda.is_available() else torch.device("cpu")
+    latent = args.image_size // 8
+    model = DiffMa_models[args.model](input_size=latent, dt_rank=args.dt_rank, d_state=args.d_state,
+                                      use_mamba2=bool(args.get("use_mamba2", False))).to(device)
+    if args.get("ckpt") and os.path.isfile(args.ckpt):
+        model.load_state_dict(find_model(args.ckpt, args.load_ckpt_type))
+    elif not args.get("synthetic", False):
+        raise FileNotFoundError(f"Could not find checkpoint at {args.ckpt}")
+    model.eval()
+    steps = int(args.sample_num_steps)
+    ddim = bool(args.get("ddim", False))
+    diffusion = create_diffusion(f"ddim{steps}" if ddim else str(steps))
+    n = int(args.sample_global_batch_size // world) or 1
+    tokens = model.x_embedder.num_patches
+    os.makedirs(args.save_dir, exist_ok=True)
+    g = torch.Generator(device=device).manual_seed(args.seed * world + rank)
+    mk = lambda *s: torch.randn(*s, generator=g, device=device)
+    out = []
+    for b in range(int(args.get("num_batches", 1))):
+        z = mk(n, 4, latent, latent)
+        kw = dict(y=mk(n, 512), y2=mk(n, tokens, 512), w=torch.sigmoid(mk(n, tokens, 1)))
+        loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
+        samples = loop(model.forward, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=device)
+        out.append(samples.cpu())
+    torch.save(torch.cat(out), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    return out
+
+
+def cli(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--config", type=str, required=True)
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--ddim", action="store_true")
+    p.add_argument("--use-mamba2", action="store_true")
+    p.add_argument("--num-batches", type=int, default=None)
+    a = p.parse_args(argv)
+    return load_config(a.config, {k: v for k, v in vars(a).items() if v is not None and k != "config"})
+
+
+if __name__ == "__main__":
+    main(cli())

@@ -1,0 +1,198 @@
+"""DDP training driver with the reference's config surface (reference train.py:90-325).
+
+    torchrun --nnodes=1 --nproc_per_node=N train.py --config config/brain.yaml [--autocast] [--use-mamba2] [--wandb]
+                                                   [--synthetic] [--max-steps K]
+
+Same YAML keys, same step (t ~ U{0..T-1}, training_losses, AdamW lr 1e-4 wd 0, EMA 0.999), same checkpoint
+dict {"model","ema","opt","args"} at results_dir/<idx>-<model>/checkpoints/<step:07d>.pt, same log line.
+Differences, all deliberate (SURVEY.md A.4-5,10):
+  * --autocast means bf16 (no GradScaler needed); the reference's fp16+GradScaler is an NVIDIA habit.
+  * a non-finite loss is detected COLLECTIVELY (all-reduce of a flag) and the step is skipped on every rank;
+    the reference `continue`s on one rank only, which dead-locks DDP.
+  * frozen encoders (SD-VAE, BiomedCLIP, CT_Encoder) need network weights: with --synthetic (the only mode
+    that can run offline) latents / embeddings / soft masks are drawn as in BASELINE.md section 4.
+"""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+from copy import deepcopy
+from glob import glob
+from time import time
+
+import torch
+import torch.distributed as dist
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+from .config import load_config
+from .diffusion import create_diffusion
+from .model import DiffMa_models
+
+
+@torch.no_grad()
+def update_ema(ema_model, model, decay=0.999):
+    ep, mp = list(ema_model.parameters()), list(model.parameters())
+    torch._foreach_mul_(ep, decay)
+    torch._foreach_add_(ep, mp, alpha=1 - decay)
+
+
+def requires_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def create_logger(logging_dir, rank):
+    logger = logging.getLogger("diffma")
+    logger.setLevel(logging.INFO)
+    logger.handlers.clear()
+    if rank == 0:
+        fmt = logging.Formatter("%(asctime)s | %(levelname)s | %(message)s", "%Y-%m-%d at %H:%M:%S")
+        sh = logging.StreamHandler()
+        sh.setFormatter(fmt)
+        logger.addHandler(sh)
+        if logging_dir:
+            fh = logging.FileHandler(f"{logging_dir}/log_0.txt")
+            fh.setFormatter(fmt)
+            logger.addHandler(fh)
+    else:
+        logger.addHandler(logging.NullHandler())
+    return logger
+
+
+class SyntheticLatents:
+    """Stand-in for NpyDataset + frozen encoders: yields (z_mri, y, y2, w) already in latent space."""
+
+    def __init__(self, n, latent, tokens, seed):
+        self.n, self.latent, self.tokens, self.seed = n, latent, tokens, seed
+
+    def batches(self, batch, device, epoch, rank, world):
+        g = torch.Generator(device=device).manual_seed(self.seed * 1000003 + epoch * 1009 + rank)
+        per_rank = self.n // world
+        for _ in range(per_rank // batch):
+            mk = lambda *s: torch.randn(*s, generator=g, device=device)
+            yield mk(batch, 4, self.latent, self.latent), mk(batch, 512), mk(batch, self.tokens, 512), torch.sigmoid(mk(batch, self.tokens, 1))
+
+
+def main(args):
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        dist.init_process_group(backend)            # torchrun env; "nccl" is RCCL on ROCm (reference load_data.py:86)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    assert args.global_batch_size % world == 0, "Batch size must be divisible by world size."
+    if torch.cuda.is_available():
+        device = torch.device("cuda", rank % torch.cuda.device_count())
+        torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
+    torch.manual_seed(args.global_seed * world + rank)
+
+    experiment_dir = checkpoint_dir = None
+    if rank == 0:
+        os.makedirs(args.results_dir, exist_ok=True)
+        idx = len(glob(f"{args.results_dir}/*"))
+        experiment_dir = f"{args.results_dir}/{idx:03d}-{args.model.replace('/', '-')}"
+        checkpoint_dir = f"{experiment_dir}/checkpoints"
+        os.makedirs(checkpoint_dir, exist_ok=True)
+    logger = create_logger(experiment_dir, rank)
+    logger.info(f"Experiment directory created at {experiment_dir}")
+
+    assert args.image_size % 8 == 0, "Image size must be divisible by 8 (for the VAE encoder)."
+    latent = args.image_size // 8
+    model = DiffMa_models[args.model](input_size=latent, dt_rank=args.dt_rank, d_state=args.d_state,
+                                      use_mamba2=bool(args.get("use_mamba2", False)))
+    train_steps = 0
+    if args.init_from_pretrain_ckpt:
+        ckpt = torch.load(args.pretrain_ckpt_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["model"])
+        ema = deepcopy(model).to(device)
+        ema.load_state_dict(ckpt["ema"] if "ema" in ckpt else ckpt["model"])
+        train_steps = args.init_train_steps
+        logger.info(f"Loaded pretrain model from {args.pretrain_ckpt_path}")
+    else:
+        ema = deepcopy(model).to(device)
+    requires_grad(ema, False)
+    model = model.to(device)
+    ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
+              bucket_cap_mb=64)
+    diffusion = create_diffusion(timestep_respacing="")
+    logger.info(f"DiffMa Parameters: {sum(p.numel() for p in model.parameters()):,}")
+    logger.info(f"Use half-precision training? {args.autocast}")
+    lr = args.lr_ if args.init_from_pretrain_ckpt else args.lr
+    opt = torch.optim.AdamW(ddp.parameters(), lr=lr, weight_decay=0, fused=device.type == "cuda")
+
+    if not args.get("synthetic", False):
+        raise RuntimeError("real-data training needs the SD-VAE / BiomedCLIP / CT_Encoder weights, which are not available "
+                           "offline; run with --synthetic (BASELINE.md section 4)")
+    tokens = model.x_embedder.num_patches
+    data = SyntheticLatents(int(args.get("synthetic_samples", 1024)), latent, tokens, args.global_seed)
+    local_batch = args.global_batch_size // world
+    logger.info(f"Dataset contains {data.n}.")
+
+    update_ema(ema, model, decay=0)                      # EMA starts as a copy of the synced weights
+    ddp.train()
+    ema.eval()
+    log_steps, running_loss, start_time = 0, 0.0, time()
+    max_steps = args.get("max_steps", None)
+    amp = torch.bfloat16 if args.autocast else None
+    logger.info(f"Training for {args.epochs} epochs...")
+    for epoch in range(args.epochs):
+        logger.info(f"Beginning epoch {epoch}...")
+        for item, (z, y, y2, w) in enumerate(data.batches(local_batch, device, epoch, rank, world), 1):
+            t = torch.randint(0, diffusion.num_timesteps, (z.shape[0],), device=device)
+            with torch.autocast(device.type, dtype=amp, enabled=amp is not None):
+                loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
+            bad = (~torch.isfinite(loss.detach())).float()
+            dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # every rank takes the same decision
+            loss.backward()                              # always run backward: keeps DDP's bucket all-reduces matched
+            if bad.item() > 0:
+                logger.info("nan......      ignore losses......")
+                opt.zero_grad(set_to_none=True)
+                continue
+            if train_steps % args.accumulation_steps == 0:
+                opt.step()
+                update_ema(ema, model)
+                opt.zero_grad(set_to_none=True)
+            running_loss += loss.item()
+            log_steps += 1
+            train_steps += 1
+            if train_steps % args.log_every == 0:
+                if device.type == "cuda":
+                    torch.cuda.synchronize()
+                steps_per_sec = log_steps / (time() - start_time)
+                avg = torch.tensor(running_loss / log_steps, device=device)
+                dist.all_reduce(avg, op=dist.ReduceOp.SUM)
+                pct = local_batch * item / data.n * 100
+                logger.info(f"({pct:.1f}%) (step={train_steps:07d}) Train Loss: {avg.item() / world:.4f}, Train Steps/Sec: {steps_per_sec:.2f}")
+                running_loss, log_steps, start_time = 0.0, 0, time()
+            if train_steps % args.ckpt_every == 0 and train_steps > 0:
+                if rank == 0:
+                    path = f"{checkpoint_dir}/{train_steps:07d}.pt"
+                    torch.save({"model": model.state_dict(), "ema": ema.state_dict(), "opt": opt.state_dict(), "args": dict(args)}, path)
+                    logger.info(f"Saved checkpoint to {path}")
+                dist.barrier()
+            if max_steps is not None and train_steps >= max_steps:
+                break
+        if max_steps is not None and train_steps >= max_steps:
+            break
+    model.eval()
+    logger.info("Done!")
+    dist.destroy_process_group()
+    return train_steps
+
+
+def cli(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--wandb", action="store_true", help="accepted for compatibility; wandb is not installed offline")
+    p.add_argument("--autocast", action="store_true", help="bf16 autocast")
+    p.add_argument("--use-mamba2", action="store_true")
+    p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning instead of datasets + frozen encoders")
+    p.add_argument("--max-steps", type=int, default=None)
+    p.add_argument("--config", type=str, required=True)
+    a = p.parse_args(argv)
+    over = {k: v for k, v in vars(a).items() if v is not None and k != "config"}
+    return load_config(a.config, over)
+
+
+if __name__ == "__main__":
+    main(cli())
