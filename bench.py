@@ -36,10 +36,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="DiffMa-L/2")
-    ap.add_argument("--batch-per-gpu", type=int, default=64)
+    ap.add_argument("--batch-per-gpu", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
-    ap.add_argument("--cpu-steps", type=int, default=2, help="training steps of the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--global-seed", type=int, default=0)
     return ap.parse_args()
 
@@ -73,6 +73,8 @@ def cpu_baseline(args, tokens):
     from diffma_amd.model import DiffMa_models
     from oracle.model_ref import diffma_forward_ref
 
+    threads = min(16, os.cpu_count() or 1)      # the op-by-op oracle does not scale past ~16 threads (tiny ops)
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     net = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
     rerandomize_zero_init(net, 1)

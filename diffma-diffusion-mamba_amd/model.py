@@ -35,9 +35,20 @@ class PatchEmbed(nn.Module):
     def forward(self, x):
         H, W = x.shape[-2:]
         assert (H, W) == self.img_size, f"Input image size ({H}*{W}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
-        x = self.proj(x)
-        if self.flatten:
-            x = x.flatten(2).transpose(1, 2)
+        ph, pw = self.patch_size
+        if self.proj.stride == (ph, pw) and self.proj.padding == (0, 0):
+            # stride == kernel: the conv is a GEMM over non-overlapping patches.  Doing it as one (MFMA) matmul keeps
+            # both passes on hipBLASLt; MIOpen's bf16 weight-gradient path for this shape is a naive kernel (2 ms/call).
+            gh, gw = self.grid_size
+            B, C = x.shape[:2]
+            xp = x[:, :, :gh * ph, :gw * pw].reshape(B, C, gh, ph, gw, pw).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, C * ph * pw)
+            x = torch.nn.functional.linear(xp, self.proj.weight.reshape(self.proj.weight.shape[0], -1), self.proj.bias)
+            if not self.flatten:
+                x = x.transpose(1, 2).reshape(B, -1, gh, gw)
+        else:
+            x = self.proj(x)
+            if self.flatten:
+                x = x.flatten(2).transpose(1, 2)
         return self.norm(x)
 
 
