@@ -137,6 +137,20 @@ def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None, re
     return _CausalConv1dFn.apply(x, weight, bias, activation is not None)
 
 
+def _tn_splitk(a, b):
+    """a^T @ b for tall operands a (M, P), b (M, Q) with tiny P*Q: the reduction runs over M = ndir*B*L
+    (150 528 at the bench shape), which hipBLASLt does not split -- a single-pass GEMM is 6-8x off its memory
+    time (measured 492 us vs 82 us, tools/bench_gemm.py).  Split K into C slabs with one bmm and add the slabs
+    in fp32."""
+    M = a.shape[0]
+    for C in (64, 32, 16, 8):
+        if M % C == 0 and M // C >= 256:
+            pa = a.view(C, M // C, a.shape[1]).transpose(1, 2)
+            pb = b.view(C, M // C, b.shape[1])
+            return torch.bmm(pa, pb).float().sum(0)
+    return (a.t() @ b).float()
+
+
 # ------------------------------------------------------------------------------------------------
 # Fused 3-direction operator of the DiffMa mixer
 # ------------------------------------------------------------------------------------------------
@@ -197,8 +211,8 @@ class _SpiralSSMFn(torch.autograd.Function):
         dx_dbl[:, :R] = ddelta2 @ Wdt.to(dt_)
         dx_dbl[:, R:R + N].copy_(dB.reshape(M, N))
         dx_dbl[:, R + N:].copy_(dC.reshape(M, N))
-        dWdt = (ddelta2.t() @ x_dbl[:, :R]).to(Wdt.dtype)                       # [Din, R]
-        dWx = (dx_dbl.t() @ xc.view(M, Din)).to(Wx.dtype)                        # [R+2N, Din]
+        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
+        dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         dxc = torch.addmm(du.view(M, Din), dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                row_index=scan_index, ndir=ndir, silu=True)
