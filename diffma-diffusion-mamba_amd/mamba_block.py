@@ -26,9 +26,9 @@ class Spiral_MambaBlock(nn.Module):
                      origina_list_reversal=origina_list_reversal)
         self.norm1 = nn.LayerNorm(D_dim)
         if use_mamba2:
-            raise NotImplementedError("--use-mamba2 (Mamba-2 SSD mixer, reference block/mamba2.py) is not built yet; "
-                                      "DESIGN.md section 8 lists it as next work")
-        mixer = Mamba
+            from .mamba2 import Mamba2 as mixer
+        else:
+            mixer = Mamba
         # NB the reference does not forward dt_rank to the mixer: dt_rank = ceil(D_dim/16)
         self.mamba1 = mixer(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, **lists)
         self.mamba2 = mixer(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, **lists)

@@ -223,6 +223,137 @@ class _SpiralSSMFn(torch.autograd.Function):
                 dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None)
 
 
+# ------------------------------------------------------------------------------------------------
+# Token-major building blocks with autograd (used by the Mamba-2 mixer)
+# ------------------------------------------------------------------------------------------------
+class _GatherConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, scan_index):
+        out = hip_ops.gather_conv1d_fwd(x, weight, bias, row_index=scan_index, ndir=scan_index.shape[0], silu=True)
+        ctx.save_for_backward(x, weight, bias, scan_index)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, bias, scan_index = ctx.saved_tensors
+        ndir = scan_index.shape[0]
+        Bsz, L, Dm = x.shape
+        dout = dout.contiguous()
+        if dout.dtype != x.dtype:
+            dout = dout.to(x.dtype)
+        dx_slabs, dw, db = hip_ops.gather_conv1d_bwd(x, weight, bias, dout, row_index=scan_index, ndir=ndir, silu=True)
+        dx = hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Dm))
+        return dx, dw.to(weight.dtype).reshape(weight.shape), (db.to(bias.dtype) if bias is not None else None), None
+
+
+def gather_conv1d(x, conv_weight, conv_bias, scan_index):
+    """x [B, L, C] token-major view -> SiLU(causal conv) of the token-gathered sequences, [ndir*B, L, C]."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _GatherConvFn.apply(x, conv_weight, conv_bias, scan_index)
+
+
+class _IndexedScanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
+        S, L, Dm = u.shape
+        N = A.shape[1]
+        need_grad = any(ctx.needs_input_grad[:8])
+        ckpt = torch.empty((S, hip_ops.scan_nchunk(L), N, Dm), dtype=torch.float32, device=u.device) if need_grad else None
+        A = A.contiguous()
+        y = hip_ops.scan_fwd(u, delta, A, Bm, Cm, D, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
+                             batch_per_dir=Bsz, ckpt=ckpt)
+        ctx.Bsz = Bsz
+        ctx.save_for_backward(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, ckpt)
+        return y.view(scan_index.shape[0], Bsz, L, Dm)
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, ckpt = ctx.saved_tensors
+        ndir, Bsz = scan_index.shape[0], ctx.Bsz
+        S, L, Dm = u.shape
+        # dy is per direction here (the merge happens after the norm), so it is read like a plain [S, L, Dm] tensor whose
+        # rows are in TOKEN order: gather rows through the table but index the batch by the sequence (batch_per_dir = 0 path
+        # is not usable), hence one kernel call per direction slab is avoided by viewing dy as ndir*B sequences.
+        dy = dy.reshape(S, L, Dm).contiguous()
+        if dy.dtype != u.dtype:
+            dy = dy.to(u.dtype)
+        dy_scan = torch.stack([dy.view(ndir, Bsz, L, Dm)[k][:, scan_index[k].long(), :] for k in range(ndir)]).reshape(S, L, Dm)
+        zg = torch.stack([z[:, scan_index[k].long(), :] for k in range(ndir)]).reshape(S, L, Dm)
+        du, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(u, delta, A, Bm, Cm, D, zg, dt_bias, dy_scan, ckpt, True)
+        dz = torch.zeros_like(z, dtype=torch.float32)
+        dzs = dzs.view(ndir, Bsz, L, Dm)
+        for k in range(ndir):
+            dz.index_add_(1, scan_index[k].long(), dzs[k].float())
+        return (du, ddelta, dA.to(A.dtype), dB.to(Bm.dtype), dC.to(Cm.dtype), dD.to(D.dtype), dz.to(z.dtype), dbias.to(dt_bias.dtype),
+                None, None)
+
+
+def indexed_scan(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
+    """Selective scan of ndir*B token-gathered sequences with the z gather and the inverse (merge) reindex folded in.
+    u, delta: [ndir*B, L, Dm]; Bm, Cm: [ndir*B, L, N] views; z: [B, L, Dm] (token order).  Returns the gated output
+    [ndir, B, L, Dm] with every direction already back in TOKEN order."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        if delta.dtype != u.dtype:
+            delta = delta.to(u.dtype)
+        if z is None:
+            raise NotImplementedError("norm_before_gate=True (ungated scan) is not wired; DiffMa uses norm_before_gate=False")
+        return _IndexedScanFn.apply(u, delta.contiguous(), A.float(), Bm, Cm, D.float(), z, dt_bias.float(), scan_index, Bsz)
+
+
+class _MergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, slabs):
+        ctx.k = slabs.shape[0]
+        return hip_ops.token_merge(slabs.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.unsqueeze(0).expand(ctx.k, *dy.shape)
+
+
+def merge_slabs(slabs):
+    """[K, B, L, Dm] -> sum over K (CrossMerge after the rows are already in token order)."""
+    return _MergeFn.apply(slabs)
+
+
+def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None,
+                                     seq_idx=None, dt_limit=(0.0, float("inf")), return_final_states=False, activation="silu",
+                                     rmsnorm_weight=None, rmsnorm_eps=1e-6, outproj_weight=None, outproj_bias=None, headdim=None,
+                                     ngroups=1, norm_before_gate=True):
+    """Drop-in for mamba_ssm's Mamba-2 fused operator with the keyword usage of block/mamba2.py:392-410.
+
+    zxbcdt: (B, L, 2*dim + 2*ngroups*N + H), columns [z | x | B | C | dt].  Single chunk (chunk_size >= L, the only case
+    DiffMa reaches: chunk_size 256, L <= 196), scalar D per head, ngroups 1.  Returns (B, L, d_model)."""
+    if initial_states is not None or seq_idx is not None or return_final_states or ngroups != 1 or headdim is None:
+        raise NotImplementedError("only the call pattern of block/mamba2.py:392-410 is built (ngroups=1, scalar D, no states)")
+    if activation not in ("silu", "swish") or dt_limit != (0.0, float("inf")):
+        raise NotImplementedError("activation must be silu and dt_limit unbounded")
+    Bsz, L, _ = zxbcdt.shape
+    if chunk_size < L:
+        raise NotImplementedError("multi-chunk SSD (chunk_size < seqlen) is never reached by DiffMa")
+    H = D.shape[0]
+    dim = H * headdim
+    N = (zxbcdt.shape[-1] - 2 * dim - H) // 2
+    if zxbcdt.stride(-1) != 1:
+        zxbcdt = zxbcdt.contiguous()
+    ident = torch.arange(L, device=zxbcdt.device, dtype=torch.int32)[None]
+    xBC = gather_conv1d(zxbcdt[..., dim:2 * dim + 2 * N], conv1d_weight, conv1d_bias, ident)
+    delta = zxbcdt[..., 2 * dim + 2 * N:].repeat_interleave(headdim, dim=-1)
+    A2 = A.float().repeat_interleave(headdim)[:, None].expand(dim, N)
+    y = indexed_scan(xBC[..., :dim], delta, A2, xBC[..., dim:dim + N], xBC[..., dim + N:], D.float().repeat_interleave(headdim),
+                     zxbcdt[..., :dim] if (rmsnorm_weight is None or not norm_before_gate) else None, dt_bias.float().repeat_interleave(headdim),
+                     ident, Bsz)[0]
+    if rmsnorm_weight is not None:
+        yf = y.float()
+        yf = yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + rmsnorm_eps) * rmsnorm_weight.float()
+        if norm_before_gate:
+            yf = yf * F.silu(zxbcdt[..., :dim].float())
+        y = yf.to(zxbcdt.dtype)
+    if outproj_weight is not None:
+        y = F.linear(y, outproj_weight.to(y.dtype), outproj_bias)
+    return y
+
+
 def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, scan_index):
     """Fused CrossScan -> 3x(conv1d+SiLU, x_proj, dt_proj, selective scan) -> CrossMerge (pre out_proj).
 

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .mamba2_ref import mamba2_spiral_forward_ref
 from .mamba_ref import mamba_spiral_forward_ref
 
 
@@ -55,7 +56,8 @@ def _timestep_embedding(t, dim, max_period=10000):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
-def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.float32, return_blocks=False):
+def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.float32, return_blocks=False, use_mamba2=False,
+                       headdim=64):
     """sd: reference-format state dict (tensors).  Inputs as DiffMa.forward (model.py:264)."""
     g = lambda k: sd[k].to(dtype)
     x = x.to(dtype)
@@ -84,8 +86,11 @@ def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.flo
         shift, scale, gate = mod.chunk(3, dim=1)
         xs = _ln(inp, g(pre + "norm1.weight"), g(pre + "norm1.bias")) * (1 + scale[:, None]) + shift[:, None]
         ws = xs * w
-        mix = lambda name, inp_: mamba_spiral_forward_ref(
-            inp_, {kk[len(pre + name) + 1:]: v for kk, v in sd.items() if kk.startswith(pre + name + ".")}, lists, dtype=dtype)
+        sub = lambda name: {kk[len(pre + name) + 1:]: v for kk, v in sd.items() if kk.startswith(pre + name + ".")}
+        if use_mamba2:
+            mix = lambda name, inp_: mamba2_spiral_forward_ref(inp_, sub(name), lists, headdim=headdim, dtype=dtype)
+        else:
+            mix = lambda name, inp_: mamba_spiral_forward_ref(inp_, sub(name), lists, dtype=dtype)
         xs, ws = mix("mamba1", xs), mix("mamba2", ws)
         cat = torch.cat([xs, ws], dim=-1)
         a = _ln(cat, g(pre + "attention_network.0.weight"), g(pre + "attention_network.0.bias"))

@@ -227,3 +227,31 @@ def test_product_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError, match="ROCm device"):
         selective_scan_fn(torch.randn(1, 64, 8), torch.randn(1, 64, 8), -torch.ones(64, 16), torch.randn(1, 16, 8),
                           torch.randn(1, 16, 8))
+
+
+# ---- G7: Mamba-2 (--use-mamba2) wiring ---------------------------------------------------------------------------------
+def test_oracle_mamba2_model_matches_reference_output():
+    from oracle.model_ref import diffma_forward_ref
+
+    g = load("g7_tiny_diffma_mamba2.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    T = lambda k: torch.from_numpy(g[k])
+    out, blocks = diffma_forward_ref(sd, T("x"), T("t"), T("y"), T("y2"), T("w"), patch_size=2, depth=4, dtype=torch.float64,
+                                     return_blocks=True, use_mamba2=True)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-4, atol=2e-6)
+    for k in range(4):
+        np.testing.assert_allclose(blocks[k].numpy(), g[f"act.block{k}"], rtol=1e-4, atol=2e-5)
+
+
+def test_product_mamba2_model_has_reference_state_dict_layout():
+    from diffma_amd.model import DiffMa
+
+    g = load("g7_tiny_diffma_mamba2.npz")
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16, use_mamba2=True)
+    own = net.state_dict()
+    assert list(own.keys()) == list(sd.keys())
+    assert all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
+    net.load_state_dict(sd)
+    m = net.blocks[0].mamba1
+    assert (m.nheads, m.headdim, m.in_proj.weight.shape[0], m.conv1d.weight.shape[0]) == (2, 64, 2 * 128 + 32 + 2, 160)

@@ -39,14 +39,25 @@ def _install_stubs():
         def __init__(self, *a, **k):
             super().__init__()
 
+    class _RMSNormGated(torch.nn.Module):       # only .weight / .eps are read by the reference (block/mamba2.py:402-403)
+        def __init__(self, hidden_size, eps=1e-5, norm_before_gate=False, group_size=None, device=None, dtype=None):
+            super().__init__()
+            self.eps = eps
+            self.weight = torch.nn.Parameter(torch.ones(hidden_size))
+
+    from oracle import mamba2_ref
+
+    def combined(zxbcdt, *a, **k):
+        return mamba2_ref.mamba_split_conv1d_scan_combined_ref(zxbcdt, *a, **k, dtype=torch.float64)
+
     mod("mamba_ssm")
     mod("mamba_ssm.ops")
     mod("mamba_ssm.ops.selective_scan_interface", selective_scan_fn=mamba_ref.selective_scan_ref, mamba_inner_fn=inner)
     mod("mamba_ssm.ops.triton")
     mod("mamba_ssm.ops.triton.selective_state_update", selective_state_update=None)
     mod("mamba_ssm.ops.triton.layernorm", RMSNorm=None, layer_norm_fn=None, rms_norm_fn=None)
-    mod("mamba_ssm.ops.triton.layernorm_gated", RMSNorm=_Dummy)
-    mod("mamba_ssm.ops.triton.ssd_combined", mamba_chunk_scan_combined=None, mamba_split_conv1d_scan_combined=None)
+    mod("mamba_ssm.ops.triton.layernorm_gated", RMSNorm=_RMSNormGated)
+    mod("mamba_ssm.ops.triton.ssd_combined", mamba_chunk_scan_combined=None, mamba_split_conv1d_scan_combined=combined)
     mod("mamba_ssm.distributed")
     mod("mamba_ssm.distributed.tensor_parallel", ColumnParallelLinear=None, RowParallelLinear=None)
     mod("mamba_ssm.distributed.distributed_utils", all_reduce=None, reduce_scatter=None)
@@ -178,6 +189,34 @@ def main():
     g5.update(loss_z=z.numpy(), loss_noise=nz.numpy(), loss_t=tt.numpy(), **{f"loss.{k}": v.numpy() for k, v in tl.items()})
     np.savez_compressed(os.path.join(OUT, "g5_tiny_diffma.npz"), **g5)
     print("G5 params", sum(p.numel() for p in net.parameters()), "out abs mean", float(out.abs().mean()))
+
+    # ---- G7 tiny DiffMa with use_mamba2=True through the reference classes (operator = oracle stub) ---------------------
+    torch.manual_seed(2025)
+    net2 = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16, use_mamba2=True)
+    gen = torch.Generator().manual_seed(199)
+    with torch.no_grad():
+        for name, p in net2.named_parameters():
+            if p.requires_grad and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+            if name.endswith("norm.weight") or name.endswith(".D"):
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+    net2.eval()
+    x = torch.randn(N, 4, 8, 8, generator=gen)
+    t = torch.tensor([7, 850])
+    y = torch.randn(N, 64, generator=gen)
+    y2 = torch.randn(N, 16, 64, generator=gen)
+    w = torch.sigmoid(torch.randn(N, 16, 1, generator=gen))
+    acts = {}
+    hooks = [blk.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(f"block{k}", o.detach().numpy())) for k, blk in enumerate(net2.blocks)]
+    with torch.no_grad():
+        out = net2(x, t, y=y, y2=y2, w=w)
+    for h in hooks:
+        h.remove()
+    g7 = {f"sd.{k}": v.numpy() for k, v in net2.state_dict().items()}
+    g7.update(x=x.numpy(), t=t.numpy(), y=y.numpy(), y2=y2.numpy(), w=w.numpy(), out=out.numpy())
+    g7.update({f"act.{k}": v for k, v in acts.items()})
+    np.savez_compressed(os.path.join(OUT, "g7_tiny_diffma_mamba2.npz"), **g7)
+    print("G7 params", sum(p.numel() for p in net2.parameters()), "out abs mean", float(out.abs().mean()))
 
     # ---- G6 operator vectors from the ORACLE (regression guard for the restatement itself) ---------------------------
     from oracle import mamba_ref
