@@ -192,6 +192,14 @@ def main():
         dom = max(ksum, key=lambda n: ksum[n]["total_ms"])
         r = ksum[dom]
         achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+        # HBM traffic of the same kernel at the same shape from the committed PMC passes (cannot be read live)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(f"{dom}:{args.dtype}")
+            if tj and tj["nseq"] == 3 * B and args.model == "DiffMa-L/2":
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": f"diffusion-steps/sec ({args.model}, 224x224, {'training' if args.mode == 'train' else '250-step DDPM sampling'}; samples*steps/s)",
             "value": round(args.steps * B * world / elapsed, 3),
@@ -206,7 +214,7 @@ def main():
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"])},
             "kernels": kernels,
         }
