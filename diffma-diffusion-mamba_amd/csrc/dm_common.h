@@ -19,6 +19,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct bf16_t { uint16_t v; };
 struct f16_t { _Float16 v; };
 
+// fp32 -> bf16 (round-to-nearest-even, NaN-safe) in ONE instruction: gfx950 has v_cvt_pk_bf16_f32 but no clang
+// builtin for it; the software sequence is 7 VALU ops per store.
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r & 0xffffu;
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -28,13 +36,7 @@ template <> struct io<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) {
         return __uint_as_float(((uint32_t)p->v) << 16);
     }
-    static __device__ __forceinline__ void st(bf16_t* p, float x) {
-        // round-to-nearest-even, NaN preserved
-        uint32_t u = __float_as_uint(x);
-        uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
-        if ((u & 0x7FFFFFFFu) > 0x7F800000u) r = u | 0x00400000u;
-        p->v = (uint16_t)(r >> 16);
-    }
+    static __device__ __forceinline__ void st(bf16_t* p, float x) { p->v = (uint16_t)f32_to_bf16_bits(x); }
 };
 template <> struct io<f16_t> {
     static __device__ __forceinline__ float ld(const f16_t* p) { return (float)p->v; }
@@ -77,9 +79,9 @@ template <> struct bio<bf16_t> {
         return __uint_as_float(((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)) << 16);
     }
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
-        bf16_t t;
-        io<bf16_t>::st(&t, x);
-        __builtin_amdgcn_raw_buffer_store_b16(t.v, r, voff, soff, 0);
+        uint32_t b;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(b) : "v"(x));       // low half is what store_b16 writes
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b, r, voff, soff, 0);
     }
 };
 template <> struct bio<f16_t> {
