@@ -25,6 +25,7 @@
 namespace dm {
 
 constexpr int BWD_CK = 8;      // must equal the forward's ckpt_every
+constexpr int BWD_SUB = 8;     // steps whose recomputed states are held at once (CK = one level, CK/2 = two-level recompute)
 constexpr int BWD_WAVES = 4;   // waves per workgroup
 
 // ---- cross-lane helpers ----------------------------------------------------------------------
@@ -87,7 +88,7 @@ __device__ __forceinline__ int opaque_i(int x) {
 
 template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS>
 __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_bwd_args p) {
-    constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = 4, M = 2 * NS, R = M / 4;
+    constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(R <= 16 / SPLIT, "not enough stager lanes per row");
@@ -291,12 +292,12 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                     yp2 += cc * hj;
                     const f32x2 G = cc * gy + carry[k];          // dL/dh_j
                     const f32x2 dCp = hj * gy;
-                    const f32x2 Gt = G * (a * hp);
+                    carry[k] = a * G;                            // a_j * dL/dh_j, flows to step j-1
+                    const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
-                    carry[k] = a * G;
                     red[2 * k] = dBp.x;
                     red[2 * k + 1] = dBp.y;
                     red[NS + 2 * k] = dCp.x;
