@@ -21,7 +21,7 @@ DM_F32, DM_BF16, DM_F16 = 0, 1, 2
 DM_FLAG_DELTA_SOFTPLUS = 1
 DM_FLAG_SILU = 2
 
-_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int}
+_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 
 
 def _parse_structs(text: str):
@@ -77,6 +77,8 @@ dm_scan_bwd_args = _make_struct("dm_scan_bwd_args")
 dm_conv_fwd_args = _make_struct("dm_conv_fwd_args")
 dm_conv_bwd_args = _make_struct("dm_conv_bwd_args")
 dm_merge_args = _make_struct("dm_merge_args")
+dm_ln_mod_args = _make_struct("dm_ln_mod_args")
+dm_blend_args = _make_struct("dm_blend_args")
 
 _lib = None
 _lock = threading.Lock()

@@ -9,8 +9,8 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_SILU, dm_conv_bwd_args,
-                   dm_conv_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args,
+                   dm_conv_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 8    # steps between saved states in training mode (= BWD_CK of scan_bwd.hip)
@@ -266,3 +266,94 @@ def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
     a.o_sb, a.o_sl = out.stride()[:2]
     _launch("dm_token_merge", a, slabs, (K * slabs.element_size() + out.element_size()) * Bsz * L * Dm)
     return out
+
+
+LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK
+
+
+def _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
+    Bsz, L, C1 = x.shape
+    C2 = x2.shape[-1] if x2 is not None else 0
+    a = dm_ln_mod_args()
+    a.batch, a.rows_per_batch, a.C1, a.C2 = Bsz, L, C1, C2
+    a.x_dtype, a.y_dtype = dtype_code(x), _DT[y_dtype]
+    mod = scale if scale is not None else mask
+    a.mod_dtype = dtype_code(mod) if mod is not None else DM_F32
+    a.eps = eps
+    a.x, a.x2, a.gamma, a.beta = _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta)
+    a.shift, a.scale, a.mask = _ptr(shift), _ptr(scale), _ptr(mask)
+    a.x_sr = x.stride(1)
+    a.x2_sr = x2.stride(1) if x2 is not None else 0
+    a.y_sr = C1 + C2
+    a.mod_sb = scale.stride(0) if scale is not None else 0
+    return a, Bsz, L, C1, C2
+
+
+def ln_mod_fwd(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
+    """LayerNorm([x|x2])*gamma+beta -> optional modulate(shift, scale per batch) -> (y1, y1*mask or None, stats)."""
+    _require_gpu(x, x2, gamma, beta, shift, scale, mask)
+    a, Bsz, L, C1, C2 = _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype)
+    C = C1 + C2
+    y1 = torch.empty((Bsz, L, C), dtype=y_dtype, device=x.device)
+    y2 = torch.empty_like(y1) if mask is not None else None
+    stats = torch.empty((Bsz * L, 2), dtype=torch.float32, device=x.device)
+    a.y1, a.y2, a.stats = _ptr(y1), _ptr(y2), _ptr(stats)
+    esz = x.element_size()
+    _launch("dm_ln_mod_fwd", a, x, Bsz * L * C * (esz + y1.element_size() * (2 if mask is not None else 1)))
+    return y1, y2, stats
+
+
+def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=None, dx2=None, accumulate=False):
+    """Returns (dx, dx2, dshift, dscale, dgamma, dbeta); dx/dx2 may be given (accumulate=True adds into them)."""
+    _require_gpu(x, dy1)
+    a, Bsz, L, C1, C2 = _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, dy1.dtype)
+    C = C1 + C2
+    if dx is None:
+        dx = torch.empty((Bsz, L, C1), dtype=x.dtype, device=x.device)
+    if x2 is not None and dx2 is None:
+        dx2 = torch.empty((Bsz, L, C2), dtype=x2.dtype, device=x.device)
+    bpb = (L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK
+    part = torch.empty((Bsz, bpb, 4, C), dtype=torch.float32, device=x.device)
+    a.stats, a.dy1, a.dy2, a.dx, a.dx2, a.part = _ptr(stats), _ptr(dy1), _ptr(dy2), _ptr(dx), _ptr(dx2), _ptr(part)
+    a.dx_sr = dx.stride(1)
+    a.dx2_sr = dx2.stride(1) if dx2 is not None else 0
+    a.accumulate = 1 if accumulate else 0
+    assert dy1.is_contiguous() and (dy2 is None or dy2.is_contiguous())
+    _launch("dm_ln_mod_bwd", a, x, Bsz * L * C * (2 * x.element_size() + dy1.element_size() * (2 if dy2 is not None else 1)))
+    pb = part.sum(1)                          # [B, 4, C]
+    dshift, dscale = pb[:, 0], pb[:, 1]
+    pg = pb.sum(0)
+    return dx, dx2, dshift, dscale, pg[2], pg[3]
+
+
+def _blend_args(x_like, xs, ws, a_row, gate):
+    Bsz, L, C = xs.shape
+    a = dm_blend_args()
+    a.batch, a.rows_per_batch, a.C = Bsz, L, C
+    a.x_dtype, a.s_dtype, a.g_dtype = dtype_code(x_like), dtype_code(xs), dtype_code(gate)
+    a.xs, a.ws, a.a, a.gate = _ptr(xs), _ptr(ws), _ptr(a_row), _ptr(gate)
+    a.gate_sb = gate.stride(0)
+    return a, Bsz, L, C
+
+
+def blend_fwd(x, xs, ws, a_row, gate):
+    """x + gate[b] * (a*xs + (1-a)*ws);  x [B,L,C] (contiguous), xs/ws [B,L,C], a_row [B,L,1], gate [B,C] view."""
+    _require_gpu(x, xs, ws, a_row, gate)
+    a, Bsz, L, C = _blend_args(x, xs, ws, a_row, gate)
+    out = torch.empty_like(x)
+    a.x, a.out = _ptr(x), _ptr(out)
+    _launch("dm_blend_fwd", a, x, Bsz * L * C * (2 * x.element_size() + 2 * xs.element_size()))
+    return out
+
+
+def blend_bwd(g, xs, ws, a_row, gate):
+    """Returns (dxs, dws, da [B,L,1], dgate [B,C] fp32)."""
+    _require_gpu(g, xs, ws, a_row, gate)
+    a, Bsz, L, C = _blend_args(g, xs, ws, a_row, gate)
+    dxs, dws = torch.empty_like(xs), torch.empty_like(ws)
+    da = torch.empty_like(a_row)
+    bpb = (L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK
+    part = torch.empty((Bsz, bpb, C), dtype=torch.float32, device=g.device)
+    a.g, a.dxs, a.dws, a.da, a.dgate_part = _ptr(g), _ptr(dxs), _ptr(dws), _ptr(da), _ptr(part)
+    _launch("dm_blend_bwd", a, g, Bsz * L * C * (g.element_size() + 4 * xs.element_size()))
+    return dxs, dws, da, part.sum(1)

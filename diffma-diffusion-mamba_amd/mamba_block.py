@@ -10,6 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import block_ops
 from .mamba import Mamba
 
 
@@ -47,8 +48,19 @@ class Spiral_MambaBlock(nn.Module):
             nn.init.constant_(self.attention_network[i].weight, 0)
             nn.init.constant_(self.attention_network[i].bias, 0)
 
+    fused_elementwise = True      # single-pass HIP kernels for the LN/modulate/mask, LN(cat) and blend chains (GPU only)
+
     def forward(self, x, c, w):
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        if self.fused_elementwise and x.is_cuda:
+            act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+            block_ops.set_output_dtype(act)
+            x_ssm, w_ssm = block_ops.ln_modulate_mask(x, self.norm1, shift, scale, w)
+            x_ssm = self.mamba1(x_ssm, "spiral")
+            w_ssm = self.mamba2(w_ssm, "spiral")
+            net = self.attention_network
+            a = net[4](net[3](net[2](net[1](block_ops.ln_cat(x_ssm, w_ssm, net[0])))))
+            return block_ops.blend_residual(x, x_ssm, w_ssm, a, gate)
         x_ssm = modulate(self.norm1(x), shift, scale)
         w_ssm = x_ssm * w
         x_ssm = self.mamba1(x_ssm, "spiral")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 4
+#define DM_ABI_VERSION 5
 
 typedef enum {
     DM_OK = 0,
@@ -204,6 +204,58 @@ typedef struct {
 } dm_merge_args;
 
 int dm_token_merge(const dm_merge_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Block elementwise ops of Spiral_MambaBlock.forward (reference block/mamba_block.py:100-115), each one
+ * HBM pass instead of a chain of ATen kernels.
+ *
+ * dm_ln_mod_fwd :  r = [x | x2] (x2 optional: the torch.cat of :111),  n = LayerNorm(r) * gamma + beta  (:103, :90),
+ *                  m = n * (1 + scale[b]) + shift[b]  (modulate, :8-9,104; skipped when scale == NULL),
+ *                  y1 = m,  y2 = m * mask[row]  (soft mask, :105; skipped when mask == NULL).
+ *                  stats[row] = {mean, rstd} (fp32) for the backward.  rows = batch * rows_per_batch.
+ * dm_ln_mod_bwd :  given dy1 (, dy2): dx (, dx2), and fp32 partial sums over groups of DM_LN_ROWS_PER_BLOCK rows
+ *                  part[blk][4][C] = {dshift, dscale, dgamma, dbeta}  (blk = b*blocks_per_batch + i);
+ *                  accumulate != 0 adds into dx/dx2 instead of overwriting (the cat branch adds to the blend's
+ *                  gradients).
+ * dm_blend_fwd  :  out = x + gate[b] * (a[row]*xs + (1-a[row])*ws)      (:113-114)
+ * dm_blend_bwd  :  dxs = g*gate*a, dws = g*gate*(1-a), da[row] = sum_c g*gate*(xs-ws),
+ *                  dgate_part[blk][C] = sum_rows g*(a*xs+(1-a)*ws)        (dx = g is the caller's)
+ * ---------------------------------------------------------------------------------------------- */
+#define DM_LN_ROWS_PER_BLOCK 28
+typedef struct {
+    int32_t batch, rows_per_batch, C1, C2;      /* C2 = 0 without x2; C = C1 + C2                          */
+    int32_t x_dtype, y_dtype, mod_dtype;        /* x/x2/dx/dx2 ; y1/y2/dy1/dy2 ; shift/scale/mask           */
+    int32_t accumulate;                         /* bwd only                                                  */
+    float eps;
+    int32_t _pad;
+    const void *x, *x2;                         /* [rows][C1], [rows][C2], row strides below                 */
+    const float *gamma, *beta;                  /* [C] or NULL (no affine)                                   */
+    const void *shift, *scale;                  /* [batch][C] rows of stride mod_sb, or NULL                 */
+    const void *mask;                           /* [rows] or NULL                                            */
+    void *y1, *y2;                              /* fwd outputs [rows][C] (y2 NULL iff mask NULL)             */
+    float *stats;                               /* [rows][2]                                                 */
+    const void *dy1, *dy2;                      /* bwd inputs                                                */
+    void *dx, *dx2;                             /* bwd outputs                                               */
+    float *part;                                /* bwd: [batch*blocks_per_batch][4][C]                       */
+    int64_t x_sr, x2_sr, y_sr, mod_sb, dx_sr, dx2_sr;
+} dm_ln_mod_args;
+
+int dm_ln_mod_fwd(const dm_ln_mod_args *args, void *stream);
+int dm_ln_mod_bwd(const dm_ln_mod_args *args, void *stream);
+
+typedef struct {
+    int32_t batch, rows_per_batch, C;
+    int32_t x_dtype, s_dtype, g_dtype;          /* x/out/g ; xs/ws/dxs/dws/a/da ; gate                       */
+    const void *x, *xs, *ws, *a, *gate;         /* gate [batch][C] rows of stride gate_sb; a [rows]          */
+    void *out;                                  /* fwd                                                       */
+    const void *g;                              /* bwd: dL/dout [rows][C]                                    */
+    void *dxs, *dws, *da;                       /* bwd                                                       */
+    float *dgate_part;                          /* bwd: [batch*blocks_per_batch][C]                          */
+    int64_t gate_sb;
+} dm_blend_args;
+
+int dm_blend_fwd(const dm_blend_args *args, void *stream);
+int dm_blend_bwd(const dm_blend_args *args, void *stream);
 
 /* Library introspection. */
 int dm_abi_version(void);

@@ -256,3 +256,47 @@ def test_mamba_split_conv1d_scan_combined_signature(gpu):
                                            **{**kw, "rmsnorm_weight": to(nw), "outproj_weight": to(ow)})
     ref = mamba_split_conv1d_scan_combined_ref(zx.double(), cw, cb, dt_bias, A, D=D, **{**kw, "rmsnorm_weight": nw, "outproj_weight": ow})
     assert got.shape == (B, L, dm) and rel_l2(got.cpu(), ref) <= 1e-4
+
+
+# ---- fused block elementwise kernels (csrc/block_ops.hip) vs the eager ATen formulation ------------------------------------
+@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+@pytest.mark.parametrize("hidden,n", [(64, 4), (512, 14)])
+def test_block_fused_elementwise_matches_eager(gpu, amp, hidden, n):
+    from diffma_amd.mamba_block import Spiral_MambaBlock
+    from diffma_amd.tools import spiral
+
+    torch.manual_seed(0)
+    orders, inverses = spiral(n)
+    blk = Spiral_MambaBlock(D_dim=hidden, E_dim=2 * hidden, dt_rank=16, dim_inner=2 * hidden, d_state=16, token_list=orders[0],
+                            token_list_reversal=orders[1], origina_list=inverses[0], origina_list_reversal=inverses[1]).to(gpu)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn_like(p) * 0.05)
+        blk.norm1.weight.add_(torch.randn_like(blk.norm1.weight) * 0.1)
+        blk.norm1.bias.add_(torch.randn_like(blk.norm1.bias) * 0.1)
+    B = 3
+    x0 = torch.randn(B, n * n, hidden, device=gpu)
+    c0 = torch.randn(B, 2 * hidden, device=gpu)
+    w = torch.sigmoid(torch.randn(B, n * n, 1, device=gpu))
+    dy = torch.randn(B, n * n, hidden, device=gpu)
+
+    def run(fused):
+        blk.fused_elementwise = fused
+        blk.zero_grad(set_to_none=True)
+        x, c = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+            y = blk(x, c, w)
+        (y.float() * dy).sum().backward()
+        return y.detach().float(), x.grad, c.grad, {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    ya, xa, ca, ga = run(True)
+    yb, xb, cb, gb = run(False)
+    tol = 2e-2 if amp else 2e-5
+    assert rel_l2(ya, yb) <= tol
+    assert rel_l2(xa, xb) <= 2 * tol and rel_l2(ca, cb) <= 2 * tol
+    for k in ga:
+        # a 1-element bf16 gradient (the fusion head's bias) is a sum with cancellation: both paths are equally far from fp32
+        lim = 3 * tol if (amp is None or ga[k].numel() >= 64) else 0.25
+        assert rel_l2(ga[k], gb[k]) <= lim, k
+    blk.fused_elementwise = True
