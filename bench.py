@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
     ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--global-seed", type=int, default=0)
+    ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
     return ap.parse_args()
 
 
@@ -151,11 +152,16 @@ def main():
         model.eval()
         sdiff = create_diffusion("250")
         state = {"x": batch["z"].clone(), "i": sdiff.num_timesteps - 1}
+        denoiser = model.forward
+        if args.graph:
+            from diffma_amd.graphed import GraphedDenoiser
+            denoiser = GraphedDenoiser(model, state["x"], torch.zeros(B, device=dev, dtype=torch.long), kw["y"], kw["y2"], kw["w"],
+                                       autocast_dtype=amp)
 
         def step():
             t = torch.full((B,), state["i"], device=dev, dtype=torch.long)
-            with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):
-                out = sdiff.p_sample(model.forward, state["x"], t, clip_denoised=False, model_kwargs=kw)
+            with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None and not args.graph):
+                out = sdiff.p_sample(denoiser, state["x"], t, clip_denoised=False, model_kwargs=kw)
             state["x"] = out["sample"].float()
             state["i"] = state["i"] - 1 if state["i"] > 0 else sdiff.num_timesteps - 1
             return out["sample"]
@@ -183,12 +189,26 @@ def main():
 
     if rank == 0:
         ksum = timer.summary()
+        kernel_source = "events on the launch stream over the timed region"
+        if not ksum and args.mode == "sample":          # hipGraph replay: launches are not visible to the host-side timer
+            hip_ops.set_timer(timer)
+            for _ in range(2):
+                t_ = torch.full((B,), 5, device=dev, dtype=torch.long)
+                with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                    model(batch["z"], t_, **kw)
+            hip_ops.set_timer(None)
+            ksum = timer.summary()
+            kernel_source = "2 eager forwards after the timed region (the timed steps replay a hipGraph)"
         kernels = {}
         for name, r in ksum.items():
             gbps = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
             kernels[name] = dict(launches_per_step=r["launches"] / args.steps, avg_us=round(r["avg_us"], 2),
                                  ms_per_step=round(r["total_ms"] / args.steps, 3), algorithmic_MB_per_launch=round(r["bytes_per_launch"] / 1e6, 3),
                                  GBps=round(gbps, 1), frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
+        nsteps_k = args.steps if "timed region" in kernel_source and "after" not in kernel_source else 2
+        for v in kernels.values():
+            v["launches_per_step"] = v["launches_per_step"] * args.steps / nsteps_k
+            v["ms_per_step"] = round(v["ms_per_step"] * args.steps / nsteps_k, 3)
         dom = max(ksum, key=lambda n: ksum[n]["total_ms"])
         r = ksum[dom]
         achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
@@ -210,12 +230,13 @@ def main():
             "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
             "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
             "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" if args.mode == "train"
-                       else f"{args.model} p_sample step, batch {B}/GPU",
+                       else f"{args.model} p_sample step (250-step respaced DDPM), batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4)},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"])},
+                         "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
+                         "timing": kernel_source},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":

@@ -55,7 +55,11 @@ def main(args):
         z = mk(n, 4, latent, latent)
         kw = dict(y=mk(n, 512), y2=mk(n, tokens, 512), w=torch.sigmoid(mk(n, tokens, 1)))
         loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
-        samples = loop(model.forward, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=device)
+        denoiser = model.forward
+        if device.type == "cuda" and not args.get("no_graph", False):
+            from .graphed import GraphedDenoiser      # shapes are static over all steps: capture once, replay per step
+            denoiser = GraphedDenoiser(model, z, torch.zeros(n, device=device, dtype=torch.long), kw["y"], kw["y2"], kw["w"])
+        samples = loop(denoiser, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=device)
         out.append(samples.cpu())
     torch.save(torch.cat(out), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))
     if dist.is_initialized():
@@ -70,6 +74,7 @@ def cli(argv=None):
     p.add_argument("--ddim", action="store_true")
     p.add_argument("--use-mamba2", action="store_true")
     p.add_argument("--num-batches", type=int, default=None)
+    p.add_argument("--no-graph", action="store_true", help="call the model eagerly instead of replaying a captured hipGraph")
     a = p.parse_args(argv)
     return load_config(a.config, {k: v for k, v in vars(a).items() if v is not None and k != "config"})
 

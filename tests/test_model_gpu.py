@@ -300,3 +300,27 @@ def test_block_fused_elementwise_matches_eager(gpu, amp, hidden, n):
         lim = 3 * tol if (amp is None or ga[k].numel() >= 64) else 0.25
         assert rel_l2(ga[k], gb[k]) <= lim, k
     blk.fused_elementwise = True
+
+
+def test_graphed_denoiser_matches_eager(gpu):
+    """hipGraph replay of the denoiser == eager call, and a full respaced p_sample_loop through it is reproducible."""
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.graphed import GraphedDenoiser
+
+    g, sd, net, inp = _g5(gpu)
+    gd = GraphedDenoiser(net, inp["x"], inp["t"], inp["y"], inp["y2"], inp["w"])
+    with torch.no_grad():
+        eager = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"])
+        x2 = torch.randn_like(inp["x"])
+        t2 = torch.tensor([500, 1], device=gpu)
+        e2 = net(x2, t2, y=inp["y"], y2=inp["y2"], w=inp["w"])
+    torch.testing.assert_close(gd(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).clone(), eager, rtol=0, atol=0)
+    torch.testing.assert_close(gd(x2, t2, y=inp["y"], y2=inp["y2"], w=inp["w"]).clone(), e2, rtol=0, atol=0)
+    d = create_diffusion("10")
+    kw = dict(y=inp["y"], y2=inp["y2"], w=inp["w"])
+    z = torch.randn(2, 4, 8, 8, device=gpu)
+    torch.manual_seed(3)
+    a = d.p_sample_loop(gd, z.shape, z, clip_denoised=False, model_kwargs=kw, device=gpu)
+    torch.manual_seed(3)
+    b = d.p_sample_loop(net.forward, z.shape, z, clip_denoised=False, model_kwargs=kw, device=gpu)
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
