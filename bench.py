@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
     ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--global-seed", type=int, default=0)
+    ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
     return ap.parse_args()
 
@@ -110,8 +111,11 @@ def main():
 
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)          # RCCL over xGMI
+    force_ddp = os.environ.get("BENCH_FORCE_DDP") == "1"          # exercise the DDP/RCCL path on a single GPU (testing only)
+    if world > 1 or force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)          # RCCL over xGMI
 
     from diffma_amd import _lib, hip_ops
     from diffma_amd.diffusion import create_diffusion
@@ -119,7 +123,7 @@ def main():
 
     _lib.load()                                                  # fail loudly if the HIP library is missing
     torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
-    model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
+    model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=args.use_mamba2)
     rerandomize_zero_init(model, 1)
     model = model.to(dev)
     tokens = model.x_embedder.num_patches
@@ -133,7 +137,7 @@ def main():
     if args.mode == "train":
         ema = copy.deepcopy(model).requires_grad_(False)
         net = model
-        if world > 1:
+        if world > 1 or force_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True)
@@ -221,7 +225,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         res = {
-            "metric": f"diffusion-steps/sec ({args.model}, 224x224, {'training' if args.mode == 'train' else '250-step DDPM sampling'}; samples*steps/s)",
+            "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else '250-step DDPM sampling'}; samples*steps/s)",
             "value": round(args.steps * B * world / elapsed, 3),
             "unit": "samples*steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -242,7 +246,7 @@ def main():
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":
             res["cpu_baseline"] = cpu_baseline(args, tokens)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         dist.destroy_process_group()
 
 
