@@ -15,7 +15,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 HEADER = os.path.join(_ROOT, "include", "diffma_hip.h")
-LIB_PATH = os.path.join(_HERE, "csrc", "libdiffma_hip.so")
+# DIFFMA_HIP_LIB: developer override used to A/B two builds of the kernels in one GPU session (tools/ab.sh)
+LIB_PATH = os.environ.get("DIFFMA_HIP_LIB") or os.path.join(_HERE, "csrc", "libdiffma_hip.so")
 
 DM_F32, DM_BF16, DM_F16 = 0, 1, 2
 DM_FLAG_DELTA_SOFTPLUS = 1

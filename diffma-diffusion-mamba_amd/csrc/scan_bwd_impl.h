@@ -4,28 +4,31 @@
 // Replaces selective_scan_cuda.bwd (autograd of mamba_inner_fn / selective_scan_fn on the training
 // path, reference train.py:259).  Equations: SURVEY.md A.1-bwd.
 //
-// Layout: token-major like the forward, but a lane owns a (channel, state-slice) pair: with SPLIT = 4 the
-// 64 lanes of a wave are 16 channels x 4 slices of d_state/4 states.  The backward needs, per lane, the
-// CK recomputed in-chunk states (hs[j] = state before step j), the adjoint carry, the dA accumulator and
-// the chunk's inputs; a whole channel per lane (16 states) is ~270 live VGPRs and spills, a 4-state slice is
-// ~100 and runs at 4+ waves/SIMD.  The price is a 2-step quad (DPP) sum of y, G.B and the dA-term per time
-// step and a replicated softplus/silu per slice.
+// Layout: token-major like the forward, but a lane owns a (channel, state-slice) pair: with SPLIT = 2 the
+// 64 lanes of a wave are 32 channels x 2 slices of d_state/2 states.  The backward needs, per lane, the
+// recomputed in-chunk states (hs[j] = state before step j), the adjoint carry, the dA accumulator and the
+// chunk's inputs; a whole channel per lane (16 states) is ~270 live VGPRs and spills.  The price is a DPP sum
+// of y, G.B and the dA-term over the slices per time step and a replicated softplus/silu per slice.
 //
 // Per chunk of CK = 8 steps (the forward saved the state entering every chunk):
-//   1. reload the state slice, recompute the CK in-chunk states in registers,
-//   2. walk the chunk backwards carrying  carry_n = a_{j+1,n} * dL/dh_{j+1,n},
+//   1. reload the state slice; two-level recompute: the states of a SUB = 4 step sub-chunk live in registers,
+//      the second sub-chunk is re-advanced from the entry state (163 VGPRs => 3 waves/SIMD; holding all 8
+//      needs 196 => 2 waves/SIMD and measures 4 % slower although it issues 7 % fewer instructions),
+//   2. walk the sub-chunk backwards carrying  carry_n = a_{j+1,n} * dL/dh_{j+1,n},
 //      accumulating dA / dD / dbias per lane (written once as per-sequence partials, no atomics),
-//   3. dB/dC: the per-lane products are reduced over the wave's 16 channels with two permlane swaps and two
-//      DPP rotations, staged in LDS, summed over the 4 waves of the workgroup after the chunk (one barrier
-//      per chunk) and stored as one row of partials per (step, 64-channel workgroup); the dim/64 workgroups
-//      of a sequence are summed by the caller (deterministic).
+//   3. dB/dC: the per-lane products are reduce-scattered over the wave's 4 lane groups (16-bit I/O: two
+//      v_mfma_f32_16x16x32_bf16 with 0/1 selector fragments on the otherwise idle matrix pipe; fp32 I/O: permlane
+//      swaps), written to LDS per row position, and after the chunk (one barrier) summed over the row positions
+//      of a slice and the 4 waves and stored as one row of partials per (step, 128-channel workgroup); the
+//      dim/128 workgroups of a sequence are summed by the caller (deterministic).
 // One sweep over u, delta, z, dout (read) and du, ddelta, dz (write): 28 B/element in fp32 + checkpoints.
+#include <type_traits>
 #include "dm_common.h"
 
 namespace dm {
 
 constexpr int BWD_CK = 8;      // must equal the forward's ckpt_every
-constexpr int BWD_SUB = 8;     // steps whose recomputed states are held at once (CK = one level, CK/2 = two-level recompute)
+constexpr int BWD_SUB = 4;     // steps whose recomputed states are held at once (CK = one level, CK/2 = two-level recompute)
 constexpr int BWD_WAVES = 4;   // waves per workgroup
 
 // ---- cross-lane helpers ----------------------------------------------------------------------
@@ -55,26 +58,47 @@ __device__ __forceinline__ float slice_sum(float x) {
     return x;
 }
 
-// v[0 .. M) per lane (M = 2*NS).  Sums over the CW = 64/SPLIT channels of the wave, i.e. over all lanes with
-// the same slice index q.  After the call register i (< M/4) of a lane holds the total of value
+// v[0 .. M) per lane (M = 2*NS).  Reduce-scatter over the 4 lane groups (16-lane rows) of the wave: after the call
+// register i (< M/4) of a lane holds the lane-group total of value
 //     4*i + 2*b4 + b5      (b5, b4 = bits 5, 4 of the lane id)
-// replicated over the lanes of its 16-lane row that share q.
-template <int M, int SPLIT>
-__device__ __forceinline__ void channel_reduce(float (&v)[M]) {
+// for its row position (lane & 15).  The sum over the row positions that share a slice is done later, in LDS.
+template <int M>
+__device__ __forceinline__ void lane_group_reduce(float (&v)[M]) {
     static_assert(M % 4 == 0, "need at least 2 states per lane");
 #pragma unroll
     for (int i = 0; i < M / 2; ++i) { swap32(v[2 * i], v[2 * i + 1]); v[i] = v[2 * i] + v[2 * i + 1]; }
 #pragma unroll
     for (int i = 0; i < M / 4; ++i) { swap16(v[2 * i], v[2 * i + 1]); v[i] = v[2 * i] + v[2 * i + 1]; }
-#pragma unroll
-    for (int i = 0; i < M / 4; ++i) {
-        v[i] += dpp<DPP_ROW_ROR + 8>(v[i]);
-        if (SPLIT <= 4) v[i] += dpp<DPP_ROW_ROR + 4>(v[i]);
-        if (SPLIT <= 2) v[i] += dpp<DPP_ROW_ROR + 2>(v[i]);
-        if (SPLIT <= 1) v[i] += dpp<DPP_ROW_ROR + 1>(v[i]);
-    }
 }
 
+// ---- matrix-pipe variant of the first two stages (16-bit I/O only) --------------------------------------
+// v_mfma_f32_16x16x32_bf16 with a 0/1 selector as the A fragment sums the B fragment over the 4 lane groups:
+// lane l supplies B[k = (l>>4, e)][j = l&15] = value e of lane l, and A[i = l&15][k = (l>>4, e)] = (e == i) gives
+// D[i][j] = sum_g value_i(lane j + 16 g).  Two instructions (values 0..7, 8..15) leave register r of lane l
+// holding the lane-group total of value 4*(l>>4) + r for row position l&15 -- the same reduce-scatter as the
+// 12 permlane swaps + 12 adds of lane_group_reduce, on the otherwise idle matrix pipe.  The products are rounded to bf16
+// first (they are re-rounded to the 16-bit I/O dtype later anyway); fp32 I/O keeps the exact VALU path.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void mfma_selectors(int lane, u32x4_t& a_lo, u32x4_t& a_hi) {
+    const int i = lane & 15;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        a_lo[p] = ((i == 2 * p) ? 0x3F80u : 0u) | ((i == 2 * p + 1) ? 0x3F800000u : 0u);
+        a_hi[p] = ((i == 2 * p + 8) ? 0x3F80u : 0u) | ((i == 2 * p + 9) ? 0x3F800000u : 0u);
+    }
+}
+__device__ __forceinline__ f32x4 mfma_group_sum16(const u32x4_t& a_lo, const u32x4_t& a_hi, const u32x4_t& v_lo, const u32x4_t& v_hi) {
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_lo), __builtin_bit_cast(bf16x8_t, v_lo), d, 0, 0, 0);
+    d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a_hi), __builtin_bit_cast(bf16x8_t, v_hi), d, 0, 0, 0);
+    return d;
+}
 // make a value opaque to the optimiser (costs no instruction): stops it from keeping the exp() / B-row
 // values of the recompute pass alive across the whole chunk just to save recomputing them
 __device__ __forceinline__ float opaque(float x) {
@@ -86,14 +110,36 @@ __device__ __forceinline__ int opaque_i(int x) {
     return x;
 }
 
+// LDS row pointer whose element offset is opaque to the optimiser (the row is RE-READ instead of being kept in
+// VGPRs across the chunk) but still known to be a multiple of 4 floats, so the reads stay ds_read_b128
+__device__ __forceinline__ const float* lds_row(const float* base, int elem_off) {
+    return reinterpret_cast<const float*>(__builtin_assume_aligned(base + opaque_i(elem_off), 16));
+}
+template <int NS>
+__device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
+    if constexpr (NS % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < NS / 4; ++k) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(row)[k];
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = row[k];
+    }
+}
+
 template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS>
-__global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_bwd_args p) {
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 3 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
+    constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M == 16;   // dB/dC lane-group sums on the matrix pipe
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
-    static_assert(R <= 16 / SPLIT, "not enough stager lanes per row");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
-    __shared__ float red_lds[2][BWD_WAVES][CK][2 * N];
+    // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
+    // that the strided reads of the chunk-end summation spread over all LDS banks
+    constexpr int RED_ROW = WAVE * R + 4 * 2 * R;
+    __shared__ __attribute__((aligned(16))) float red_lds[BWD_WAVES][CK][RED_ROW];
     __shared__ __attribute__((aligned(16))) float bc_lds[2][CK][2 * N];   // [B row | C row] of every step of a chunk, all waves share a sequence
 
     const int tid = threadIdx.x;
@@ -123,7 +169,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
     const TBC* __restrict__ Cg = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
     const rsrc_t r_ck = make_rsrc(p.ckpt ? p.ckpt + (int64_t)s * nchunk * N * p.dim : nullptr);
     const int vo = d * ES;                 // per-lane byte offset of the channel, shared by all T tensors
-    const int vo_ck = d * 4;
+    const int vo_ck = (d + q * NS * p.dim) * 4;     // the slice offset is per lane: keep it in the VGPR part of the address
     const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_g = (int)p.do_sl * ES;
     const int sl_du = (int)p.du_sl * ES, sl_ddt = (int)p.ddt_sl * ES, sl_dz = (int)p.dz_sl * ES;
     const int i_B_sl = (int)p.B_sl, i_C_sl = (int)p.C_sl;
@@ -144,11 +190,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
     for (int k = 0; k < NPL; ++k) { carry[k] = (f32x2){0.f, 0.f}; dA[k] = (f32x2){0.f, 0.f}; }
     float dD_acc = 0.f, dbias_acc = 0.f;
 
-    // which reduced register this lane stages in LDS, and where
-    const int jrow = (lane & 15) / SPLIT;                         // index of the lane among its row's same-q lanes
-    const int vidx = 4 * jrow + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);      // value index in [0, M) if jrow < R
-    const int col = (vidx < NS) ? (q * NS + vidx) : (N + q * NS + vidx - NS);   // [dB(0..N) | dC(0..N)]
-    const bool stager = jrow < R;
+    u32x4_t sel_lo, sel_hi;
+    if (MFMA_RED) mfma_selectors(lane, sel_lo, sel_hi);
+    const int red_slot = lane * R + (lane >> 4) * 2 * R;
 
     // B/C rows of a chunk: CK*2N values, fetched cooperatively (one or two per thread), one chunk ahead
     constexpr int BC_PER_THREAD = (CK * 2 * N + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);
@@ -170,6 +214,27 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
             if (e < CK * 2 * N) bc_lds[b][e / (2 * N)][e % (2 * N)] = v[i];
         }
     };
+    // sum chunk `chunk`'s staged products over the workgroup's waves and over the row positions of a slice,
+    // and store its dB/dC partial rows
+    auto flush_dbc = [&](int chunk) {
+        const int l0 = chunk * CK;
+        for (int e = tid; e < CK * 2 * N; e += 64 * BWD_WAVES) {
+            const int j = e / (2 * N), cc = e % (2 * N);
+            if (l0 + j < L) {
+                const int n = (cc < N) ? cc : cc - N;
+                const int qq = n / NS;
+                const int vidx = (cc < N) ? n % NS : NS + n % NS;                 // value index in [0, M) inside slice qq
+                const int lane0 = (MFMA_RED ? 16 * (vidx >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
+                const int reg = MFMA_RED ? (vidx & 3) : (vidx >> 2);
+                float acc = 0.f;
+#pragma unroll
+                for (int w = 0; w < BWD_WAVES; ++w)
+#pragma unroll
+                    for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(lane0 + SPLIT * t) * R + (lane0 >> 4) * 2 * R + reg];
+                p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
+            }
+        }
+    };
     {
         float v[BC_PER_THREAD];
         fetch_bc(nchunk - 1, v);
@@ -182,27 +247,31 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
         const int l0 = ch * CK;
         float bc_next[BC_PER_THREAD];
         if (ch > 0) fetch_bc(ch - 1, bc_next);          // lands while this chunk computes
-        // ---- chunk inputs (invalid tail steps become exact no-ops: dl = u = g = 0) -------------------
+        // ---- chunk inputs (invalid tail steps become exact no-ops: g = 0 => every adjoint term is 0) ------
         float uu[CK], dl[CK], zz[CK], gg[CK];
-        int zrow[CK];
+        int zrow[CK], orow_[CK];
+        if (IDX && l0 + CK <= L) {                          // full chunk: the 8 table entries come as one scalar vector load each
+            typedef int i32x8_t __attribute__((ext_vector_type(8)));
+            typedef const i32x8_t __attribute__((address_space(4), aligned(4)))* idx8_ptr;
+            const i32x8_t zi = *(idx8_ptr)(zidx + l0), oi = *(idx8_ptr)(oidx + l0);
+#pragma unroll
+            for (int j = 0; j < CK; ++j) { zrow[j] = zi[j]; orow_[j] = oi[j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CK; ++j) {
+                const int l = (l0 + j < L) ? l0 + j : L - 1;
+                zrow[j] = IDX ? zidx[l] : l;
+                orow_[j] = IDX ? oidx[l] : l;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
             const int l = (l0 + j < L) ? l0 + j : L - 1;
-            zrow[j] = IDX ? zidx[l] : l;
-            const int orow = IDX ? oidx[l] : l;
+            const int orow = orow_[j];
             uu[j] = bio<T>::ld(r_u, vo, l * sl_u);
             dl[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
             zz[j] = HAS_Z ? bio<T>::ld(r_z, vo, zrow[j] * sl_z) : 0.f;
             gg[j] = bio<T>::ld(r_g, vo, orow * sl_g);
-        }
-#pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            const bool valid = (l0 + j) < L;
-            float x = dl[j] + bias;
-            if (SOFTPLUS) x = softplus_f(x);
-            dl[j] = valid ? x : 0.f;
-            uu[j] = valid ? uu[j] : 0.f;
-            gg[j] = (valid && active) ? gg[j] : 0.f;
         }
         // ---- state slice entering the chunk ---------------------------------------------------------
         f32x2 h0[NPL];
@@ -212,17 +281,24 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
         } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                h0[k].x = bio<float>::ld(r_ck, vo_ck, ((ch * N + q * NS + 2 * k) * p.dim) * 4);
-                h0[k].y = bio<float>::ld(r_ck, vo_ck, ((ch * N + q * NS + 2 * k + 1) * p.dim) * 4);
+                h0[k].x = bio<float>::ld(r_ck, vo_ck, ((ch * N + 2 * k) * p.dim) * 4);
+                h0[k].y = bio<float>::ld(r_ck, vo_ck, ((ch * N + 2 * k + 1) * p.dim) * 4);
             }
         }
 
+#pragma unroll
+        for (int j = 0; j < CK; ++j) {
+            const bool valid = (l0 + j) < L;
+            float x = dl[j] + bias;
+            if (SOFTPLUS) x = softplus_f(x);
+            dl[j] = x;                                    // tail steps re-read row L-1: finite garbage that only meets g = 0
+            gg[j] = (valid && active) ? gg[j] : 0.f;
+        }
         // one forward step of the slice: h <- a*h + B*dl*u   (used by all three recompute passes)
         auto fwd_step = [&](f32x2(&h)[NPL], int j) {
             float Bv[NS];
-            const float* brow = &bc_lds[0][0][0] + opaque_i((buf * CK + j) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
-#pragma unroll
-            for (int k = 0; k < NS; ++k) Bv[k] = brow[k];
+            const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
+            lds_ld_vec<NS>(Bv, brow);
             const float dlo = opaque(dl[j]);
             const float du = dlo * uu[j];
 #pragma unroll
@@ -238,7 +314,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
             }
         };
 
-        // Two-level recompute: sub-chunks of SUB steps, last one first.  The states of ONE sub-chunk live
+        // Recompute in sub-chunks of SUB steps, last one first.  The states of ONE sub-chunk live
         // in registers (hs); earlier sub-chunks are re-advanced from the chunk's entry state when needed.
 #pragma unroll
         for (int sc = CK / SUB - 1; sc >= 0; --sc) {
@@ -262,12 +338,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                 const bool valid = lraw < L;                    // wave-uniform
                 const int l = valid ? lraw : L - 1;
                 float Bv[NS], Cv[NS];
-                const float* brow = &bc_lds[0][0][0] + opaque_i((buf * CK + j) * 2 * N + q * NS);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    Bv[k] = brow[k];
-                    Cv[k] = brow[N + k];
-                }
+                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);
+                lds_ld_vec<NS>(Bv, brow);
+                lds_ld_vec<NS>(Cv, brow + N);
                 const float g = gg[j];
                 float sz = 1.f, gy = g;
                 if (HAS_Z) {
@@ -278,6 +351,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                 const float du = dlo * uu[j];
                 f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
                 float red[M];
+                u32x4_t pk_dB, pk_dC;
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     f32x2 bb, cc;
@@ -296,12 +370,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                     const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
+                    dA[k].x = opaque(dA[k].x);                   // accumulate NOW: left alone the scheduler defers all 8 steps'
+                    dA[k].y = opaque(dA[k].y);                   // products to the chunk end and keeps 64 VGPRs alive for them
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
-                    red[2 * k] = dBp.x;
-                    red[2 * k + 1] = dBp.y;
-                    red[NS + 2 * k] = dCp.x;
-                    red[NS + 2 * k + 1] = dCp.y;
+                    if constexpr (MFMA_RED) {
+                        pk_dB[k] = pack_bf16(dBp.x, dBp.y);
+                        pk_dC[k] = pack_bf16(dCp.x, dCp.y);
+                    } else {
+                        red[2 * k] = dBp.x;
+                        red[2 * k + 1] = dBp.y;
+                        red[NS + 2 * k] = dCp.x;
+                        red[NS + 2 * k + 1] = dCp.y;
+                    }
                     h[k] = hp;
                 }
                 const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[j];
@@ -322,24 +403,23 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void scan_bwd_kernel(const dm_scan_
                         bio<T>::st(r_dz, vo, zrow[j] * sl_dz, dzv);
                     }
                 }
-                channel_reduce<M, SPLIT>(red);
-                float val = red[0];
+                if constexpr (MFMA_RED) {
+                    const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, pk_dB, pk_dC);
+                    *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot]) = dsum;
+                } else {
+                    lane_group_reduce<M>(red);
 #pragma unroll
-                for (int r = 1; r < R; ++r) val = (jrow == r) ? red[r] : val;
-                if (stager) red_lds[buf][wave][j][col] = val;
+                    for (int r4 = 0; r4 < R / 4; ++r4)
+                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot + 4 * r4]) = (f32x4){red[4 * r4], red[4 * r4 + 1], red[4 * r4 + 2], red[4 * r4 + 3]};
+                    if constexpr (R % 4 != 0) {
+#pragma unroll
+                        for (int r = R - R % 4; r < R; ++r) red_lds[wave][j][red_slot + r] = red[r];
+                    }
+                }
             }
         }
-        // ---- sum the workgroup's waves' dB/dC rows of this chunk and store them --------------------------
         __syncthreads();
-        for (int e = tid; e < CK * 2 * N; e += 64 * BWD_WAVES) {
-            const int j = e / (2 * N), cc = e % (2 * N);
-            if (l0 + j < L) {
-                float acc = 0.f;
-#pragma unroll
-                for (int w = 0; w < BWD_WAVES; ++w) acc += red_lds[buf][w][j][cc];
-                p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
-            }
-        }
+        flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);
         __syncthreads();
         buf ^= 1;

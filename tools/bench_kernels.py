@@ -70,6 +70,18 @@ def main():
             nbytes = 7 * S * Dm * L * s + 2 * S * N * L * s
             print(json.dumps(dict(kernel="scan_bwd(+partial sums)", S=S, dtype=args.dtype, us=t * 1e6, GBps=nbytes / t / 1e9,
                                   Gelem_s=S * Dm * L / t / 1e9)), flush=True)
+        if want("scan_idx") and S % 3 == 0:
+            # the model's call: 3 directions x batch in one launch, z / dout shared and read through the row-index table
+            Bd = S // 3
+            K = hip_ops.SCAN_CKPT_EVERY
+            idx = torch.stack([torch.arange(L), torch.randperm(L), torch.randperm(L)]).to(torch.int32).to(dev)
+            zb, doutb = z[:Bd].contiguous(), torch.randn(Bd, L, Dm, device=dev).to(dt)
+            ckpt = torch.empty(S, hip_ops.scan_nchunk(L, K), N, Dm, device=dev)
+            kw = dict(z_row_index=idx, out_row_index=idx, batch_per_dir=Bd)
+            t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, zb, bias, True, out=out, ckpt=ckpt, ckpt_every=K, **kw), args.iters)
+            print(json.dumps(dict(kernel="scan_fwd_idx_ckpt", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
+            t = timeit(lambda: hip_ops.scan_bwd(u, delta, A, Bm, Cm, Dp, zb, bias, doutb, ckpt, True, ckpt_every=K, **kw), args.iters)
+            print(json.dumps(dict(kernel="scan_bwd_idx(+partial sums)", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
         if not (want("conv") or want("merge") or want("copy")):
             continue
         # conv (3 directions) : reads x once per direction, writes 3 outputs
