@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
     ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--global-seed", type=int, default=0)
+    ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
+                    help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): recorded table / library default / time unseen shapes")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
     return ap.parse_args()
@@ -122,6 +124,10 @@ def main():
     from diffma_amd.model import DiffMa_models
 
     _lib.load()                                                  # fail loudly if the HIP library is missing
+    if args.gemm_tuning != "off":
+        from diffma_amd import gemm_tuning
+        gemm_tuning.enable_tuned_gemms(tune_missing=args.gemm_tuning == "tune",
+                                       write_file=os.path.join(os.getcwd(), "gpurun_out", f"gemm_tuning_rank{rank}.csv"))
     torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
     model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=args.use_mamba2)
     rerandomize_zero_init(model, 1)
@@ -236,7 +242,7 @@ def main():
             "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" if args.mode == "train"
                        else f"{args.model} p_sample step (250-step respaced DDPM), batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
-                       "optimizer_steps_per_sec": round(args.steps / elapsed, 4)},
+                       "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),

@@ -1,0 +1,39 @@
+"""hipBLASLt / rocBLAS solution selection for the GEMMs around the scan (in_proj, x_proj, dt_proj, out_proj,
+adaLN, fusion MLP and their backward).
+
+The libraries' default heuristics pick poor kernels for DiffMa's tall-skinny shapes (M = batch*196 rows against
+K, N in {32, 64, 512, 1024, 2048}): e.g. `in_proj` 182 us by default vs 93 us for the best solution, and
+`ddelta @ W_dt` 187 us vs 59 us.  PyTorch's TunableOp times every solution of both libraries once per shape
+and records the winner; `tuned/gemm_gfx950.csv` holds those records for the bench / training shapes
+(DiffMa-L/2, 256 samples per GPU; made by `tools/tune_gemm.sh`).  The file is keyed by the library build
+(validator lines), so on any other ROCm build PyTorch ignores it and falls back to the default heuristics.
+
+This only configures the vendor BLAS; nothing here touches the reference's API surface.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+
+TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
+
+
+def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = False, write_file: str | None = None) -> bool:
+    """Use the recorded GEMM solutions.  tune_missing=True additionally times unseen shapes on first use (adds
+    ~1 s per new shape; worthwhile for long training runs) and, with write_file, saves the merged table.
+    Returns False (and changes nothing) when no GPU is present."""
+    if not torch.cuda.is_available():
+        return False
+    import torch.cuda.tunable as tunable
+    path = results_file or os.environ.get("DIFFMA_GEMM_TUNING_FILE") or TUNED_FILE
+    tunable.enable(True)
+    tunable.tuning_enable(bool(tune_missing))
+    if tune_missing:
+        tunable.set_max_tuning_duration(20)
+        tunable.set_filename(write_file or os.path.join(os.getcwd(), "diffma_gemm_tuning.csv"), False)
+    else:
+        tunable.set_filename(path, False)
+    if os.path.exists(path):
+        tunable.read_file(path)
+    return True

@@ -17,7 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import spiral_ssm
+from .selective_scan_interface import linear_splitk, spiral_ssm
 
 
 class Mamba(nn.Module):
@@ -75,8 +75,8 @@ class Mamba(nn.Module):
             raise NotImplementedError("autoregressive decode is never used by a diffusion model")
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
-        xz = F.linear(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
+        xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
         A = -torch.exp(self.A_log.float())
         y = spiral_ssm(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                        self.dt_proj.bias, A, self.D, self.scan_index)
-        return F.linear(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)
+        return linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import gather_conv1d, indexed_scan, merge_slabs
+from .selective_scan_interface import gather_conv1d, indexed_scan, linear_splitk, merge_slabs
 
 
 class RMSNorm(nn.Module):
@@ -95,7 +95,7 @@ class Mamba2(nn.Module):
         Bsz, L, _ = u.shape
         Din, N, H, P = self.d_inner, self.d_state, self.nheads, self.headdim
         ndir = self.scan_index.shape[0]
-        zxbcdt = F.linear(u, self.in_proj.weight, self.in_proj.bias)             # [B, L, 2*Din + 2N + H], token-major
+        zxbcdt = linear_splitk(u, self.in_proj.weight, self.in_proj.bias)             # [B, L, 2*Din + 2N + H], token-major
         z = zxbcdt[..., :Din]
         xBC = gather_conv1d(zxbcdt[..., Din:2 * Din + 2 * N], self.conv1d.weight, self.conv1d.bias, self.scan_index)   # [ndir*B, L, Din+2N]
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
@@ -109,4 +109,4 @@ class Mamba2(nn.Module):
         y = indexed_scan(x, delta, A, Bm, Cm, Dskip, z, dt_bias, self.scan_index, Bsz)      # [ndir, B, L, Din] token order, gated by silu(z)
         y = self.norm(y)                                                          # row-wise: commutes with the token permutation
         y = merge_slabs(y)                                                        # [B, L, Din]
-        return F.linear(y.to(zxbcdt.dtype), self.out_proj.weight, self.out_proj.bias)
+        return linear_splitk(y.to(zxbcdt.dtype), self.out_proj.weight, self.out_proj.bias)

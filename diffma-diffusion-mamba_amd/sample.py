@@ -34,6 +34,9 @@ def main(args):
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     device = torch.device("cuda", rank % torch.cuda.device_count()) if torch.cuda.is_available() else torch.device("cpu")
+    if device.type == "cuda":
+        from .gemm_tuning import enable_tuned_gemms
+        enable_tuned_gemms()
     latent = args.image_size // 8
     model = DiffMa_models[args.model](input_size=latent, dt_rank=args.dt_rank, d_state=args.d_state,
                                       use_mamba2=bool(args.get("use_mamba2", False))).to(device)

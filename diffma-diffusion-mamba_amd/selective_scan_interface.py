@@ -138,17 +138,51 @@ def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None, re
 
 
 def _tn_splitk(a, b):
-    """a^T @ b for tall operands a (M, P), b (M, Q) with tiny P*Q: the reduction runs over M = ndir*B*L
-    (150 528 at the bench shape), which hipBLASLt does not split -- a single-pass GEMM is 6-8x off its memory
-    time (measured 492 us vs 82 us, tools/bench_gemm.py).  Split K into C slabs with one bmm and add the slabs
-    in fp32."""
+    """a^T @ b for tall operands a (M, P), b (M, Q): the reduction runs over M = B*L or ndir*B*L (50 176 /
+    150 528 at the bench shape), which hipBLASLt does not split -- a single-pass GEMM is 2-8x off its memory
+    time (x_proj: 492 us vs 82 us; in_proj: 194 us vs 128 us even after solution tuning; tools/bench_gemm.py).
+    Split K into C slabs with one bmm and add the slabs in fp32; C is bounded so that the slab outputs stay
+    small next to the operands."""
     M = a.shape[0]
     for C in (64, 32, 16, 8):
-        if M % C == 0 and M // C >= 256:
+        if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23):
             pa = a.view(C, M // C, a.shape[1]).transpose(1, 2)
             pb = b.view(C, M // C, b.shape[1])
             return torch.bmm(pa, pb).float().sum(0)
     return (a.t() @ b).float()
+
+
+class _LinearSplitKFn(torch.autograd.Function):
+    """F.linear whose weight gradient uses the split-K product above (the projections' dW GEMMs have K = B*L)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        dev = x.device.type
+        dt_ = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
+        xc = x if x.dtype == dt_ else x.to(dt_)
+        wc = weight if weight.dtype == dt_ else weight.to(dt_)
+        ctx.save_for_backward(xc, wc)
+        ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        return F.linear(xc, wc, None if bias is None else bias.to(dt_))
+
+    @staticmethod
+    def backward(ctx, dy):
+        xc, wc = ctx.saved_tensors
+        x_dt, w_dt, b_dt = ctx.meta
+        with torch.autocast(device_type=xc.device.type, enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            if dy2.dtype != xc.dtype:
+                dy2 = dy2.to(xc.dtype)
+            x2 = xc.reshape(-1, xc.shape[-1])
+            dx = (dy2 @ wc).view(xc.shape).to(x_dt) if ctx.needs_input_grad[0] else None
+            dw = _tn_splitk(dy2.contiguous(), x2.contiguous()).to(w_dt) if ctx.needs_input_grad[1] else None
+            db = dy2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear_splitk(x, weight, bias=None):
+    """Drop-in for F.linear(x, weight, bias) on the token-major projections (in_proj / out_proj)."""
+    return _LinearSplitKFn.apply(x, weight, bias)
 
 
 # ------------------------------------------------------------------------------------------------

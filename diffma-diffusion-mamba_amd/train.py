@@ -86,6 +86,9 @@ def main(args):
     else:
         device = torch.device("cpu")
     torch.manual_seed(args.global_seed * world + rank)
+    if device.type == "cuda":
+        from .gemm_tuning import enable_tuned_gemms
+        enable_tuned_gemms(tune_missing=True)       # long run: timing an unseen GEMM shape once (~1 s) pays for itself
 
     experiment_dir = checkpoint_dir = None
     if rank == 0:

@@ -48,3 +48,13 @@ for C in (8, 16, 32, 64, 128, 256):
 ref = (xdbl.float().t() @ xc.float())
 got = splitk(xdbl, xc, 64)
 print("dWx splitK rel err vs fp32:", float((got - ref).norm() / ref.norm()), " plain bf16 gemm rel err:", float(((xdbl.t() @ xc).float() - ref).norm() / ref.norm()))
+
+# weight gradients of the wide projections (K = B*L = 50176 rows): plain GEMM vs split-K
+Mp = M // 3
+dY = torch.randn(Mp, 2048, device=dev, dtype=dt); Xp = torch.randn(Mp, 512, device=dev, dtype=dt)
+dYo = torch.randn(Mp, 512, device=dev, dtype=dt); Xo = torch.randn(Mp, 1024, device=dev, dtype=dt)
+print(json.dumps({"in_proj dW plain (2048,M)@(M,512)": round(timeit(lambda: dY.t() @ Xp), 1),
+                  "out_proj dW plain (512,M)@(M,1024)": round(timeit(lambda: dYo.t() @ Xo), 1)}))
+for C in (4, 8, 16, 32):
+    print(json.dumps({"C": C, "in_proj dW splitK": round(timeit(lambda: splitk(dY, Xp, C)), 1),
+                      "out_proj dW splitK": round(timeit(lambda: splitk(dYo, Xo, C)), 1)}))
