@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--global-seed", type=int, default=0)
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
                     help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): recorded table / library default / time unseen shapes")
+    ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
     return ap.parse_args()
@@ -178,6 +179,19 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if args.torch_profile and rank == 0:
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        with open(args.torch_profile, "w") as f:
+            f.write(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=60))
+            f.write("\n\n== copies / reductions / elementwise by input shape ==\n")
+            rows = [e for e in prof.key_averages(group_by_input_shape=True)
+                    if e.key in ("aten::copy_", "aten::sum", "aten::add_", "aten::add", "aten::mul", "aten::fill_", "aten::zero_", "aten::cat")]
+            rows.sort(key=lambda e: -e.device_time_total)
+            for e in rows[:40]:
+                f.write(f"{e.key:14s} n={e.count:4d} dev_us={e.device_time_total:10.1f}  {str(e.input_shapes)[:150]}\n")
     timer = hip_ops.KernelTimer()
     if world > 1:
         dist.barrier()

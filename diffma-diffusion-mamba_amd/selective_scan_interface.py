@@ -247,7 +247,8 @@ class _SpiralSSMFn(torch.autograd.Function):
         dx_dbl[:, R + N:].copy_(dC.reshape(M, N))
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
-        dxc = torch.addmm(du.view(M, Din), dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)
+        # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
+        dxc = du.view(M, Din).addmm_(dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                row_index=scan_index, ndir=ndir, silu=True)
         dxz = torch.empty_like(xz)
