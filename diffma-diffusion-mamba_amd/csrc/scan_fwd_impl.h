@@ -53,7 +53,7 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 // IDX : z_row_index / out_row_index tables are used (both non-null)
 // CKPT: h is written to p.ckpt every p.ckpt_every steps (a multiple of PF)
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF>
-__global__ __launch_bounds__(64) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : 1))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
     static_assert(N % 2 == 0, "d_state must be even");
     static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
     constexpr int NP = N / 2;
