@@ -2,6 +2,7 @@
 #include "dm_common.h"
 namespace dm {
 constexpr int BWD_CK = 8;
+constexpr int BWD_SUB = 4;     // = checkpoint spacing (scan_bwd_impl.h)
 int scan_bwd_f32(const dm_scan_bwd_args& a, hipStream_t st);
 int scan_bwd_bf16(const dm_scan_bwd_args& a, hipStream_t st);
 int scan_bwd_f16(const dm_scan_bwd_args& a, hipStream_t st);
@@ -17,8 +18,11 @@ extern "C" int dm_selective_scan_bwd(const dm_scan_bwd_args* args, void* stream)
     if ((a.z != nullptr) != (a.dz != nullptr)) { set_error("dm_selective_scan_bwd: dz must be given iff z is"); return DM_ERR_ARG; }
     if (a.nseq <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ngroups <= 0) { set_error("dm_selective_scan_bwd: non-positive size"); return DM_ERR_ARG; }
     if (a.nseq > 65535) { set_error("dm_selective_scan_bwd: nseq %d > 65535", a.nseq); return DM_ERR_ARG; }
-    if (a.ckpt_every != BWD_CK) { set_error("dm_selective_scan_bwd: ckpt_every must be %d", BWD_CK); return DM_ERR_ARG; }
-    if (!a.ckpt && a.seqlen > BWD_CK) { set_error("dm_selective_scan_bwd: ckpt required for seqlen > %d", BWD_CK); return DM_ERR_ARG; }
+    if (a.ckpt_every != BWD_SUB) { set_error("dm_selective_scan_bwd: ckpt_every must be %d", BWD_SUB); return DM_ERR_ARG; }
+    if (!a.ckpt && a.seqlen > BWD_SUB) { set_error("dm_selective_scan_bwd: ckpt required for seqlen > %d", BWD_SUB); return DM_ERR_ARG; }
+    if (a.ckpt && a.ckpt_dtype != (a.io_dtype == DM_BF16 ? DM_BF16 : DM_F32)) {
+        set_error("dm_selective_scan_bwd: ckpt_dtype must be DM_BF16 for bf16 I/O and DM_F32 otherwise"); return DM_ERR_DTYPE;
+    }
     if (a.u_sd != 1 || a.dt_sd != 1 || a.do_sd != 1 || a.du_sd != 1 || a.ddt_sd != 1 || (a.z && (a.z_sd != 1 || a.dz_sd != 1)) ||
         a.B_sn != 1 || a.C_sn != 1) {
         set_error("dm_selective_scan_bwd: needs token-major tensors (channel stride 1, state stride 1)"); return DM_ERR_LAYOUT;

@@ -10,10 +10,10 @@
 // chunk's inputs; a whole channel per lane (16 states) is ~270 live VGPRs and spills.  The price is a DPP sum
 // of y, G.B and the dA-term over the slices per time step and a replicated softplus/silu per slice.
 //
-// Per chunk of CK = 8 steps (the forward saved the state entering every chunk):
-//   1. reload the state slice; two-level recompute: the states of a SUB = 4 step sub-chunk live in registers,
-//      the second sub-chunk is re-advanced from the entry state (163 VGPRs => 3 waves/SIMD; holding all 8
-//      needs 196 => 2 waves/SIMD and measures 4 % slower although it issues 7 % fewer instructions),
+// Per staging chunk of CK = 8 steps:
+//   1. per SUB = 4 step sub-chunk: reload the state slice from the forward's checkpoint (every 4 steps; bf16 pairs
+//      for bf16 I/O, i.e. the same bytes as fp32 every 8) and recompute the 4 in-chunk states into registers
+//      (163 VGPRs => 3 waves/SIMD; holding 8 states needs 196 => 2 waves/SIMD and measures slower),
 //   2. walk the sub-chunk backwards carrying  carry_n = a_{j+1,n} * dL/dh_{j+1,n},
 //      accumulating dA / dD / dbias per lane (written once as per-sequence partials, no atomics),
 //   3. dB/dC: the per-lane products are reduce-scattered over the wave's 4 lane groups (16-bit I/O: two
@@ -27,8 +27,8 @@
 
 namespace dm {
 
-constexpr int BWD_CK = 8;      // must equal the forward's ckpt_every
-constexpr int BWD_SUB = 4;     // steps whose recomputed states are held at once (CK = one level, CK/2 = two-level recompute)
+constexpr int BWD_CK = 8;      // steps per staging chunk (B/C rows and dB/dC partials go through LDS once per chunk)
+constexpr int BWD_SUB = 4;     // checkpoint spacing = steps whose recomputed states are held in registers at once
 constexpr int BWD_WAVES = 4;   // waves per workgroup
 
 // ---- cross-lane helpers ----------------------------------------------------------------------
@@ -167,9 +167,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     const rsrc_t r_dz = make_rsrc(HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);
     const TBC* __restrict__ Bg = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
     const TBC* __restrict__ Cg = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
-    const rsrc_t r_ck = make_rsrc(p.ckpt ? p.ckpt + (int64_t)s * nchunk * N * p.dim : nullptr);
+    // checkpoints: the state entering every SUB-step sub-chunk; fp32 rows [n][d] or, for bf16 I/O, rows [n/2][d] of bf16 pairs
+    constexpr bool CK_PACKED = std::is_same<T, bf16_t>::value;
+    constexpr int CK_ROWS = CK_PACKED ? N / 2 : N;
+    const int nck = (L + SUB - 1) / SUB;
+    const rsrc_t r_ck = make_rsrc(p.ckpt ? (const uint32_t*)p.ckpt + (int64_t)s * nck * CK_ROWS * p.dim : nullptr);
     const int vo = d * ES;                 // per-lane byte offset of the channel, shared by all T tensors
-    const int vo_ck = (d + q * NS * p.dim) * 4;     // the slice offset is per lane: keep it in the VGPR part of the address
+    const int vo_ck = (d + q * (CK_ROWS / SPLIT) * p.dim) * 4;   // the slice offset is per lane: keep it in the VGPR part of the address
     const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_g = (int)p.do_sl * ES;
     const int sl_du = (int)p.du_sl * ES, sl_ddt = (int)p.ddt_sl * ES, sl_dz = (int)p.dz_sl * ES;
     const int i_B_sl = (int)p.B_sl, i_C_sl = (int)p.C_sl;
@@ -273,16 +277,26 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             zz[j] = HAS_Z ? bio<T>::ld(r_z, vo, zrow[j] * sl_z) : 0.f;
             gg[j] = bio<T>::ld(r_g, vo, orow * sl_g);
         }
-        // ---- state slice entering the chunk ---------------------------------------------------------
-        f32x2 h0[NPL];
-        if (ch == 0) {
+        // ---- state slices entering the chunk's sub-chunks (sub-chunk 0 of the sequence and sub-chunks past the end: 0) ----
+        // (packed checkpoints stay raw until the sub-chunk starts: unpacking here would put a vmcnt(0) right behind every load)
+        constexpr int H0W = CK_PACKED ? NPL : 2 * NPL;               // 32-bit words per sub-chunk state slice
+        uint32_t h0w[CK / SUB][H0W];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) h0[k] = (f32x2){0.f, 0.f};
-        } else {
+        for (int sc = 0; sc < CK / SUB; ++sc) {
+            const int ci = ch * (CK / SUB) + sc;
+            if (ci == 0 || ci * SUB >= L) {
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                h0[k].x = bio<float>::ld(r_ck, vo_ck, ((ch * N + 2 * k) * p.dim) * 4);
-                h0[k].y = bio<float>::ld(r_ck, vo_ck, ((ch * N + 2 * k + 1) * p.dim) * 4);
+                for (int k = 0; k < H0W; ++k) h0w[sc][k] = 0u;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    if constexpr (CK_PACKED) {
+                        h0w[sc][k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * (N / 2) + k) * p.dim) * 4, 0);
+                    } else {
+                        h0w[sc][2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * N + 2 * k) * p.dim) * 4, 0);
+                        h0w[sc][2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * N + 2 * k + 1) * p.dim) * 4, 0);
+                    }
+                }
             }
         }
 
@@ -314,15 +328,21 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
         };
 
-        // Recompute in sub-chunks of SUB steps, last one first.  The states of ONE sub-chunk live
-        // in registers (hs); earlier sub-chunks are re-advanced from the chunk's entry state when needed.
+        // Sub-chunks of SUB steps, last one first; each starts from its own checkpoint and its SUB states live in
+        // registers (hs) during its reverse sweep.
 #pragma unroll
         for (int sc = CK / SUB - 1; sc >= 0; --sc) {
             f32x2 h[NPL];
 #pragma unroll
-            for (int k = 0; k < NPL; ++k) h[k] = h0[k];
-#pragma unroll
-            for (int j = 0; j < sc * SUB; ++j) fwd_step(h, j);           // advance to the sub-chunk start
+            for (int k = 0; k < NPL; ++k) {
+                if constexpr (CK_PACKED) {
+                    h[k].x = __uint_as_float(h0w[sc][k] << 16);
+                    h[k].y = __uint_as_float(h0w[sc][k] & 0xffff0000u);
+                } else {
+                    h[k].x = __uint_as_float(h0w[sc][2 * k]);
+                    h[k].y = __uint_as_float(h0w[sc][2 * k + 1]);
+                }
+            }
             f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {

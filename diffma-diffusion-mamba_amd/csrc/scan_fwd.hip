@@ -2,6 +2,7 @@
 #include "dm_common.h"
 namespace dm {
 constexpr int SCAN_PF = 8;
+constexpr int FWD_CKE = 4;      // checkpoint spacing (scan_fwd_impl.h)
 int scan_fwd_f32(const dm_scan_fwd_args& a, hipStream_t st);
 int scan_fwd_bf16(const dm_scan_fwd_args& a, hipStream_t st);
 int scan_fwd_f16(const dm_scan_fwd_args& a, hipStream_t st);
@@ -28,8 +29,11 @@ extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream)
     if (a.batch_per_dir > 0 && a.nseq % a.batch_per_dir != 0) {
         set_error("dm_selective_scan_fwd: nseq %% batch_per_dir != 0"); return DM_ERR_ARG;
     }
-    if (a.ckpt && (a.ckpt_every <= 0 || a.ckpt_every % SCAN_PF != 0)) {
-        set_error("dm_selective_scan_fwd: ckpt_every must be a positive multiple of %d", SCAN_PF); return DM_ERR_ARG;
+    if (a.ckpt && a.ckpt_every != FWD_CKE) {
+        set_error("dm_selective_scan_fwd: ckpt_every must be %d", FWD_CKE); return DM_ERR_ARG;
+    }
+    if (a.ckpt && a.ckpt_dtype != (a.io_dtype == DM_BF16 ? DM_BF16 : DM_F32)) {
+        set_error("dm_selective_scan_fwd: ckpt_dtype must be DM_BF16 for bf16 I/O and DM_F32 otherwise"); return DM_ERR_DTYPE;
     }
     if ((a.z_row_index == nullptr) != (a.out_row_index == nullptr)) {
         set_error("dm_selective_scan_fwd: z_row_index and out_row_index must both be set or both be NULL"); return DM_ERR_ARG;

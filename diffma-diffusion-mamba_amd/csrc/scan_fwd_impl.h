@@ -23,6 +23,8 @@
 
 namespace dm {
 
+constexpr int FWD_CKE = 4;     // steps between checkpoints (the backward's sub-chunk length)
+
 // One time step of the recurrence for one lane.
 template <int N, bool HAS_Z, bool SOFTPLUS>
 __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[N / 2], const float (&Bv)[N],
@@ -51,7 +53,7 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 }
 
 // IDX : z_row_index / out_row_index tables are used (both non-null)
-// CKPT: h is written to p.ckpt every p.ckpt_every steps (a multiple of PF)
+// CKPT: the state is written to p.ckpt after every FWD_CKE = 4 steps (fp32, or bf16 pairs for bf16 I/O)
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : 1))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
     static_assert(N % 2 == 0, "d_state must be even");
@@ -109,9 +111,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
 #pragma unroll
     for (int j = 0; j < NP; ++j) h[j] = (f32x2){0.0f, 0.0f};
 
-    const int K = CKPT ? p.ckpt_every : 1;
-    const int nchunk = CKPT ? (L + K - 1) / K : 0;
-    const rsrc_t r_ck = make_rsrc(CKPT ? p.ckpt + (int64_t)s * nchunk * N * p.dim : nullptr);
+    constexpr bool CK_PACKED = std::is_same<T, bf16_t>::value;      // checkpoint = pairs of bf16 in one 32-bit word
+    constexpr int CK_ROWS = CK_PACKED ? NP : N;                     // 32-bit rows of [dim] per checkpoint
+    const int nchunk = CKPT ? (L + FWD_CKE - 1) / FWD_CKE : 0;
+    const rsrc_t r_ck = make_rsrc(CKPT ? (const uint32_t*)p.ckpt + (int64_t)s * nchunk * CK_ROWS * p.dim : nullptr);
+    auto store_ckpt = [&](int done) {                               // done = steps finished (wave-uniform)
+        if (done < L) {                                             // state entering chunk done / FWD_CKE
+            const int c = done / FWD_CKE;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if constexpr (CK_PACKED) {
+                    uint32_t w;
+                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
+                    __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((c * NP + k) * p.dim) * 4, 0);
+                } else {
+                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
+                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
+                }
+            }
+        }
+    };
 
     // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
     float ru[PF], rd[PF], rz[PF];
@@ -166,17 +185,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
             }
             const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
-        }
-        if (CKPT) {
-            const int done = l0 + PF;                 // steps finished; wave-uniform
-            if (done % K == 0 && done < L) {          // state entering chunk done/K
-                const int c = done / K;
-#pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
-                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
-                }
-            }
+            if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l0 + j + 1);      // l0 is a multiple of PF
         }
         buf ^= 1;
         stash_bc(buf, nbc);
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
             }
             const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
+            if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l + 1);
         }
     }
 
@@ -225,6 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
 }
 
 constexpr int SCAN_PF = 8;
+static_assert(SCAN_PF % FWD_CKE == 0, "checkpoints fall on fixed positions of a prefetch block");
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_fwd3(const dm_scan_fwd_args& a, hipStream_t st, dim3 grid) {

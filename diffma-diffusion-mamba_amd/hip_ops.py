@@ -13,7 +13,7 @@ from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_SILU
                    dm_conv_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
-SCAN_CKPT_EVERY = 8    # steps between saved states in training mode (= BWD_CK of scan_bwd.hip)
+SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
 
 
 class KernelTimer:
@@ -94,6 +94,20 @@ def scan_nchunk(L: int, every: int = SCAN_CKPT_EVERY) -> int:
     return (L + every - 1) // every
 
 
+def alloc_scan_ckpt(S: int, L: int, N: int, Dm: int, io_dtype, device):
+    """Checkpoint buffer of the training forward (include/diffma_hip.h): bf16 I/O stores pairs of bf16 states in
+    one 32-bit word ([S, chunk, N/2, Dm] int32), every other I/O dtype stores fp32 ([S, chunk, N, Dm])."""
+    if io_dtype == torch.bfloat16:
+        return torch.empty((S, scan_nchunk(L), N // 2, Dm), dtype=torch.int32, device=device)
+    return torch.empty((S, scan_nchunk(L), N, Dm), dtype=torch.float32, device=device)
+
+
+def _ckpt_dtype_code(ckpt):
+    if ckpt is None:
+        return DM_F32
+    return DM_BF16 if ckpt.dtype == torch.int32 else DM_F32
+
+
 def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
              ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1):
@@ -115,6 +129,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.bc_dtype = dtype_code(Bm)
     a.flags = DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0
     a.ckpt_every = ckpt_every
+    a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
     a.B, a.C, a.A, a.D, a.delta_bias = _ptr(Bm), _ptr(Cm), _ptr(A), _ptr(D), _ptr(delta_bias)
     a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
@@ -130,7 +145,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     es = u.element_size()
     nbytes = 4 * S * Dm * L * es - (0 if z is not None else S * Dm * L * es) + 2 * S * N * L * Bm.element_size() + 4 * Dm * N + 8 * Dm
     if ckpt is not None:
-        nbytes += (scan_nchunk(L, ckpt_every) - 1) * S * N * Dm * 4
+        nbytes += (scan_nchunk(L, ckpt_every) - 1) * S * ckpt.shape[2] * Dm * 4
     _launch("dm_selective_scan_fwd", a, u, nbytes)
     return out
 
@@ -167,6 +182,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.bc_dtype = dtype_code(Bm)
     a.flags = DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0
     a.ckpt_every = ckpt_every
+    a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.dout = _ptr(u), _ptr(delta), _ptr(z), _ptr(dout)
     a.B, a.C, a.A, a.D, a.delta_bias = _ptr(Bm), _ptr(Cm), _ptr(A32), _ptr(D32), _ptr(b32)
     a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
@@ -187,7 +203,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
     es = u.element_size()
     nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
-        + (scan_nchunk(L, ckpt_every) - 1) * S * N * Dm * 4
+        + (scan_nchunk(L, ckpt_every) - 1) * S * (ckpt.shape[2] if ckpt is not None else N) * Dm * 4
     _launch("dm_selective_scan_bwd", a, u, nbytes)
     dBCs = dBC.sum(dim=2)                       # [S, L, 2N] fp32, deterministic
     dB, dC = dBCs[..., :N], dBCs[..., N:]

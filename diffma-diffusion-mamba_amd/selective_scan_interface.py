@@ -57,7 +57,7 @@ class _SelectiveScanFn(torch.autograd.Function):
         need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
         ckpt = None
         if need_grad:
-            ckpt = torch.empty((S, hip_ops.scan_nchunk(L), N, Dm), dtype=torch.float32, device=ut.device)
+            ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, ut.dtype, ut.device)
         last = torch.empty((S, N, Dm), dtype=torch.float32, device=ut.device) if return_last_state else None
         out = hip_ops.scan_fwd(ut, dt, A, Bt, Ct, D, zt, delta_bias, delta_softplus, ckpt=ckpt, last_state=last,
                                ngroups=G)
@@ -214,7 +214,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         ckpt = None
         if need_grad:
-            ckpt = torch.empty((ndir * Bsz, hip_ops.scan_nchunk(L), N, Din), dtype=torch.float32, device=xz.device)
+            ckpt = hip_ops.alloc_scan_ckpt(ndir * Bsz, L, N, Din, xz.dtype, xz.device)
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
                                 out_row_index=scan_index, batch_per_dir=Bsz, ckpt=ckpt)             # token order
         y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din))
@@ -293,7 +293,7 @@ class _IndexedScanFn(torch.autograd.Function):
         S, L, Dm = u.shape
         N = A.shape[1]
         need_grad = any(ctx.needs_input_grad[:8])
-        ckpt = torch.empty((S, hip_ops.scan_nchunk(L), N, Dm), dtype=torch.float32, device=u.device) if need_grad else None
+        ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, u.dtype, u.device) if need_grad else None
         A = A.contiguous()
         y = hip_ops.scan_fwd(u, delta, A, Bm, Cm, D, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
                              batch_per_dir=Bsz, ckpt=ckpt)

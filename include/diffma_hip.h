@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 5
+#define DM_ABI_VERSION 6
 
 typedef enum {
     DM_OK = 0,
@@ -64,7 +64,10 @@ enum {
  * row out_row_index[dir*seqlen + l]: the CrossMerge inverse reindex is folded into the store
  * (block/mamba.py:59-69).  With ndir = 1 and both index pointers NULL this is the plain operator.
  *
- * ckpt (optional, training): h after every ckpt_every steps, fp32, layout [s][chunk][n][d].
+ * ckpt (optional, training): the state after every ckpt_every (= 4) steps; chunk c holds the state entering
+ * step 4*c (chunk 0 is never written).  ckpt_dtype DM_F32: fp32, layout [s][chunk][n][d] (fp32 / fp16 I/O);
+ * DM_BF16: pairs of bf16 in one 32-bit word, layout [s][chunk][n/2][d], state 2k in the low half and 2k+1 in
+ * the high half (bf16 I/O: the recomputed states inherit the precision the I/O tensors already have).
  * last_state (optional): final h, fp32, layout [s][n][d].
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -75,6 +78,7 @@ typedef struct {
     int32_t bc_dtype;        /* dm_dtype of B, C                                       */
     int32_t flags;
     int32_t ckpt_every;      /* steps between checkpoints (only read when ckpt != 0)   */
+    int32_t ckpt_dtype;      /* DM_F32 or DM_BF16 (see above)                          */
     const void *u, *delta, *z;   /* z may be NULL */
     void *out;
     const void *B, *C;
@@ -83,7 +87,7 @@ typedef struct {
     const float *delta_bias; /* [dim] fp32 or NULL             */
     const int32_t *z_row_index;   /* [ndir][seqlen] or NULL */
     const int32_t *out_row_index; /* [ndir][seqlen] or NULL */
-    float *ckpt;             /* or NULL */
+    void *ckpt;              /* or NULL */
     float *last_state;       /* or NULL */
     /* element strides; the channel stride of u/delta/z/out and the state stride of B/C must be 1 */
     int64_t u_ss, u_sl, u_sd;
@@ -116,12 +120,13 @@ typedef struct {
     int32_t bc_dtype;
     int32_t flags;
     int32_t ckpt_every;
+    int32_t ckpt_dtype;
     const void *u, *delta, *z, *dout;
     const void *B, *C;
     const float *A, *D, *delta_bias;
     const int32_t *z_row_index;
     const int32_t *out_row_index;
-    const float *ckpt;       /* required */
+    const void *ckpt;        /* required */
     void *du, *ddelta, *dz;  /* dz NULL iff z NULL; same dtype as u */
     float *dBC_partial;      /* [nseq][seqlen][ceil(dim/GC)][2*dstate] */
     float *dA_partial;       /* [nseq][dim][dstate]              */

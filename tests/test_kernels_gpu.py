@@ -84,9 +84,9 @@ def test_scan_fwd_row_index_and_checkpoints(gpu):
     zsrc = torch.randn(Bsz, L, Dm, generator=g)
     perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
     operms = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
-    K = 16
+    K = hip_ops.SCAN_CKPT_EVERY
     nch = hip_ops.scan_nchunk(L, K)
-    ckpt = torch.zeros(S, nch, N, Dm, device=gpu)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, torch.float32, gpu).zero_()
     out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zsrc.to(gpu), d["bias"], True,
                            z_row_index=perms.to(gpu), out_row_index=operms.to(gpu), batch_per_dir=Bsz,
                            ckpt=ckpt, ckpt_every=K)
@@ -181,8 +181,7 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
     host, d = _inputs(S, L, Dm, N, dtype, seed=seed, dev=gpu, with_z=with_z and not indexed)
     g = torch.Generator().manual_seed(seed + 1)
     K = hip_ops.SCAN_CKPT_EVERY
-    nch = hip_ops.scan_nchunk(L, K)
-    ckpt = torch.zeros(S, nch, N, Dm, device=gpu)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_()
     kw = {}
     if indexed:
         ndir = S // Bsz

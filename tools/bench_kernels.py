@@ -61,7 +61,7 @@ def main():
             res.append(r)
         if want("scan_bwd"):
             K = hip_ops.SCAN_CKPT_EVERY
-            ckpt = torch.empty(S, hip_ops.scan_nchunk(L, K), N, Dm, device=dev)
+            ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dt, dev)
             hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out, ckpt=ckpt, ckpt_every=K)
             t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=out, ckpt=ckpt, ckpt_every=K), args.iters)
             print(json.dumps(dict(kernel="scan_fwd_ckpt", S=S, dtype=args.dtype, us=t * 1e6, Gelem_s=S * Dm * L / t / 1e9)), flush=True)
@@ -76,7 +76,7 @@ def main():
             K = hip_ops.SCAN_CKPT_EVERY
             idx = torch.stack([torch.arange(L), torch.randperm(L), torch.randperm(L)]).to(torch.int32).to(dev)
             zb, doutb = z[:Bd].contiguous(), torch.randn(Bd, L, Dm, device=dev).to(dt)
-            ckpt = torch.empty(S, hip_ops.scan_nchunk(L, K), N, Dm, device=dev)
+            ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dt, dev)
             kw = dict(z_row_index=idx, out_row_index=idx, batch_per_dir=Bd)
             t = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, zb, bias, True, out=out, ckpt=ckpt, ckpt_every=K, **kw), args.iters)
             print(json.dumps(dict(kernel="scan_fwd_idx_ckpt", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
