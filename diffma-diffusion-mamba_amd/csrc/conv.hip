@@ -9,58 +9,101 @@
 // chunk issues all CH+W-1 row loads up front (deep memory-level parallelism), then slides the W-tap
 // window through registers.  Algorithmic bytes: read x once per direction + write out = 2*s B/element
 // per direction (halo re-reads of W-1 rows per chunk are L2 hits).
+#include <initializer_list>
 #include "dm_common.h"
 
 namespace dm {
 
 constexpr int CONV_CH = 14;   // time steps per wave chunk (196 = 14*14)
 
-template <typename T, typename TW, int W, bool SILU>
+// VEC channels per lane: 16-bit I/O moves 2 channels per 32-bit access (half the memory instructions per byte;
+// the 16-bit version is issue-bound: 3.8 vs 5.7 TB/s-equivalent measured against fp32 I/O).
+template <typename T, int VEC> struct vio;
+template <typename T> struct vio<T, 1> {
+    static __device__ __forceinline__ void ld(const T* p, float (&v)[1]) { v[0] = io<T>::ld(p); }
+    static __device__ __forceinline__ void st(T* p, const float (&v)[1]) { io<T>::st(p, v[0]); }
+};
+template <> struct vio<bf16_t, 2> {
+    static __device__ __forceinline__ void ld(const bf16_t* p, float (&v)[2]) {
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+        v[0] = __uint_as_float(w << 16);
+        v[1] = __uint_as_float(w & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[2]) {
+        uint32_t w;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[0]), "v"(v[1]));
+        *reinterpret_cast<uint32_t*>(p) = w;
+    }
+};
+template <> struct vio<f16_t, 2> {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void ld(const f16_t* p, float (&v)[2]) {
+        const h2 w = *reinterpret_cast<const h2*>(p);
+        v[0] = (float)w.x;
+        v[1] = (float)w.y;
+    }
+    static __device__ __forceinline__ void st(f16_t* p, const float (&v)[2]) {
+        h2 w;
+        w.x = (_Float16)v[0];
+        w.y = (_Float16)v[1];
+        *reinterpret_cast<h2*>(p) = w;
+    }
+};
+
+template <typename T, typename TW, int W, bool SILU, int VEC>
 __global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) {
     const int lane = threadIdx.x;
-    const int d0 = blockIdx.x * WAVE;
+    const int d0 = blockIdx.x * WAVE * VEC;
     const int c = blockIdx.y;
     const int s = blockIdx.z;               // dir*batch + b
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
-    const bool active = (d0 + lane) < p.dim;
-    const int d = active ? d0 + lane : p.dim - 1;
+    const bool active = (d0 + lane * VEC) < p.dim;          // dim % VEC == 0 (dispatch)
+    const int d = active ? d0 + lane * VEC : p.dim - VEC;
     const int lbeg = c * CONV_CH;
 
     const T* __restrict__ xp = (const T*)p.x + (int64_t)b * p.x_sb + d;
     T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss + d;
     const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
 
-    float w[W];
+    float w[W][VEC], bias[VEC];
 #pragma unroll
-    for (int j = 0; j < W; ++j) w[j] = io<TW>::ld((const TW*)p.weight + (int64_t)d * W + j);
-    const float bias = p.bias ? io<TW>::ld((const TW*)p.bias + d) : 0.0f;
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) w[j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(d + v) * W + j);
+        bias[v] = p.bias ? io<TW>::ld((const TW*)p.bias + d + v) : 0.0f;
+    }
 
     // rows lbeg-(W-1) .. lbeg+CH-1 ; out-of-range rows contribute zero
-    T raw[CONV_CH + W - 1];
+    float xv[CONV_CH + W - 1][VEC];
 #pragma unroll
     for (int j = 0; j < CONV_CH + W - 1; ++j) {
         int l = lbeg - (W - 1) + j;
         l = l < 0 ? 0 : (l >= L ? L - 1 : l);
         const int r = idx ? idx[l] : l;
-        raw[j] = xp[(int64_t)r * p.x_sl];
+        vio<T, VEC>::ld(xp + (int64_t)r * p.x_sl, xv[j]);
     }
-    float xv[CONV_CH + W - 1];
 #pragma unroll
-    for (int j = 0; j < CONV_CH + W - 1; ++j) {
-        const int l = lbeg - (W - 1) + j;
-        xv[j] = (l >= 0) ? io<T>::ld(&raw[j]) : 0.0f;
+    for (int j = 0; j < W - 1; ++j) {
+        if (lbeg - (W - 1) + j < 0) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) xv[j][v] = 0.0f;
+        }
     }
 #pragma unroll
     for (int j = 0; j < CONV_CH; ++j) {
         const int l = lbeg + j;
         if (l < L) {
-            float acc = bias;
+            float acc[VEC];
 #pragma unroll
-            for (int k = 0; k < W; ++k) acc += w[k] * xv[j + k];
-            if (SILU) acc = silu_f(acc);
-            if (active) io<T>::st(op + (int64_t)l * p.o_sl, acc);
+            for (int v = 0; v < VEC; ++v) {
+                acc[v] = bias[v];
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc[v] += w[k][v] * xv[j + k][v];
+                if (SILU) acc[v] = silu_f(acc[v]);
+            }
+            if (active) vio<T, VEC>::st(op + (int64_t)l * p.o_sl, acc);
         }
     }
 }
@@ -68,17 +111,17 @@ __global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) 
 // Backward: g[m] = dout[m]*act'(pre[m]);  dxs[m] = sum_j w[j]*g[m+W-1-j]  written at token idx[m];
 // dw[j] += g[m]*x[idx[m-(W-1)+j]];  db += g[m].   A chunk needs pre/g on [lbeg, lbeg+CH+W-1) and x
 // on [lbeg-(W-1), lbeg+CH+W-1).
-template <typename T, typename TW, int W, bool SILU>
+template <typename T, typename TW, int W, bool SILU, int VEC>
 __global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) {
     const int lane = threadIdx.x;
-    const int d0 = blockIdx.x * WAVE;
+    const int d0 = blockIdx.x * WAVE * VEC;
     const int c = blockIdx.y;
     const int s = blockIdx.z;
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
-    const bool active = (d0 + lane) < p.dim;
-    const int d = active ? d0 + lane : p.dim - 1;
+    const bool active = (d0 + lane * VEC) < p.dim;
+    const int d = active ? d0 + lane * VEC : p.dim - VEC;
     const int lbeg = c * CONV_CH;
     constexpr int NG = CONV_CH + W - 1;        // g positions lbeg .. lbeg+NG-1
     constexpr int NX = CONV_CH + 2 * (W - 1);  // x positions lbeg-(W-1) .. lbeg+NG-1
@@ -88,97 +131,142 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) 
     T* __restrict__ dxp = (T*)p.dx + (int64_t)s * p.dx_ss + d;
     const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
 
-    float w[W];
+    float w[W][VEC], bias[VEC];
 #pragma unroll
-    for (int j = 0; j < W; ++j) w[j] = io<TW>::ld((const TW*)p.weight + (int64_t)d * W + j);
-    const float bias = p.bias ? io<TW>::ld((const TW*)p.bias + d) : 0.0f;
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) w[j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(d + v) * W + j);
+        bias[v] = p.bias ? io<TW>::ld((const TW*)p.bias + d + v) : 0.0f;
+    }
 
-    T rawx[NX], rawg[NG];
+    float xv[NX][VEC], g[NG][VEC];
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         int l = lbeg - (W - 1) + j;
         l = l < 0 ? 0 : (l >= L ? L - 1 : l);
         const int r = idx ? idx[l] : l;
-        rawx[j] = xp[(int64_t)r * p.x_sl];
+        vio<T, VEC>::ld(xp + (int64_t)r * p.x_sl, xv[j]);
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         int l = lbeg + j;
         l = l >= L ? L - 1 : l;
-        rawg[j] = gp[(int64_t)l * p.do_sl];
+        vio<T, VEC>::ld(gp + (int64_t)l * p.do_sl, g[j]);
     }
-    float xv[NX];
 #pragma unroll
     for (int j = 0; j < NX; ++j) {
         const int l = lbeg - (W - 1) + j;
-        xv[j] = (l >= 0 && l < L) ? io<T>::ld(&rawx[j]) : 0.0f;
-    }
-    float g[NG];
-    float dw[W];
+        if (l < 0 || l >= L) {
 #pragma unroll
-    for (int j = 0; j < W; ++j) dw[j] = 0.0f;
-    float db = 0.0f;
+            for (int v = 0; v < VEC; ++v) xv[j][v] = 0.0f;
+        }
+    }
+    float dw[W][VEC], db[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) dw[j][v] = 0.0f;
+        db[v] = 0.0f;
+    }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int l = lbeg + j;
-        float gv = 0.0f;
-        if (l < L) {
-            gv = io<T>::ld(&rawg[j]);
-            if (SILU) {
-                float pre = bias;
 #pragma unroll
-                for (int k = 0; k < W; ++k) pre += w[k] * xv[j + k];
-                const float sg = sigmoid_f(pre);
-                gv *= sg * (1.0f + pre * (1.0f - sg));
-            }
-            if (j < CONV_CH) {   // each position's parameter gradient is owned by exactly one chunk
+        for (int v = 0; v < VEC; ++v) {
+            float gv = 0.0f;
+            if (l < L) {
+                gv = g[j][v];
+                if (SILU) {
+                    float pre = bias[v];
 #pragma unroll
-                for (int k = 0; k < W; ++k) dw[k] += gv * xv[j + k];
-                db += gv;
+                    for (int k = 0; k < W; ++k) pre += w[k][v] * xv[j + k][v];
+                    const float sg = sigmoid_f(pre);
+                    gv *= sg * (1.0f + pre * (1.0f - sg));
+                }
+                if (j < CONV_CH) {   // each position's parameter gradient is owned by exactly one chunk
+#pragma unroll
+                    for (int k = 0; k < W; ++k) dw[k][v] += gv * xv[j + k][v];
+                    db[v] += gv;
+                }
             }
+            g[j][v] = gv;
         }
-        g[j] = gv;
     }
 #pragma unroll
     for (int j = 0; j < CONV_CH; ++j) {
         const int m = lbeg + j;
         if (m < L) {
-            float acc = 0.0f;
+            float acc[VEC];
 #pragma unroll
-            for (int k = 0; k < W; ++k) acc += w[k] * g[j + (W - 1) - k];
+            for (int v = 0; v < VEC; ++v) {
+                acc[v] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < W; ++k) acc[v] += w[k][v] * g[j + (W - 1) - k][v];
+            }
             const int r = idx ? idx[m] : m;
-            if (active) io<T>::st(dxp + (int64_t)r * p.dx_sl, acc);
+            if (active) vio<T, VEC>::st(dxp + (int64_t)r * p.dx_sl, acc);
         }
     }
     if (active) {
         float* dwp = p.dw_partial + (((int64_t)s * p.nchunk + c) * p.dim + d) * W;
 #pragma unroll
-        for (int k = 0; k < W; ++k) dwp[k] = dw[k];
-        if (p.db_partial) p.db_partial[((int64_t)s * p.nchunk + c) * p.dim + d] = db;
+        for (int v = 0; v < VEC; ++v) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dwp[v * W + k] = dw[k][v];
+            if (p.db_partial) p.db_partial[((int64_t)s * p.nchunk + c) * p.dim + d + v] = db[v];
+        }
     }
+}
+
+static inline bool even4(const void* ptr, std::initializer_list<int64_t> strides, int dim) {
+    if (((uintptr_t)ptr & 3) || (dim & 1)) return false;
+    for (int64_t st : strides) if (st & 1) return false;
+    return true;
+}
+
+template <typename T, typename TW, int W, int VEC>
+static void launch_conv_fwd_v(const dm_conv_fwd_args& a, hipStream_t st) {
+    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
+    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), nchunk, a.ndir * a.batch), block(WAVE);
+    if (a.flags & DM_FLAG_SILU)
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, a);
 }
 
 template <typename T, typename TW, int W>
 static int launch_conv_fwd(const dm_conv_fwd_args& a, hipStream_t st) {
-    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
-    dim3 grid((a.dim + WAVE - 1) / WAVE, nchunk, a.ndir * a.batch), block(WAVE);
-    if (a.flags & DM_FLAG_SILU)
-        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, true>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, false>), grid, block, 0, st, a);
+    if constexpr (sizeof(T) == 2) {
+        if (even4(a.x, {a.x_sb, a.x_sl}, a.dim) && even4(a.out, {a.o_ss, a.o_sl}, a.dim)) launch_conv_fwd_v<T, TW, W, 2>(a, st);
+        else launch_conv_fwd_v<T, TW, W, 1>(a, st);
+    } else {
+        launch_conv_fwd_v<T, TW, W, 1>(a, st);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_gather_conv1d_fwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
 }
 
+template <typename T, typename TW, int W, int VEC>
+static void launch_conv_bwd_v(const dm_conv_bwd_args& a, hipStream_t st) {
+    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
+    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), nchunk, a.ndir * a.batch), block(WAVE);
+    if (a.flags & DM_FLAG_SILU)
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, a);
+}
+
 template <typename T, typename TW, int W>
 static int launch_conv_bwd(const dm_conv_bwd_args& a, hipStream_t st) {
-    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
-    dim3 grid((a.dim + WAVE - 1) / WAVE, nchunk, a.ndir * a.batch), block(WAVE);
-    if (a.flags & DM_FLAG_SILU)
-        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, false>), grid, block, 0, st, a);
+    if constexpr (sizeof(T) == 2) {
+        if (even4(a.x, {a.x_sb, a.x_sl}, a.dim) && even4(a.dout, {a.do_ss, a.do_sl}, a.dim) && even4(a.dx, {a.dx_ss, a.dx_sl}, a.dim))
+            launch_conv_bwd_v<T, TW, W, 2>(a, st);
+        else
+            launch_conv_bwd_v<T, TW, W, 1>(a, st);
+    } else {
+        launch_conv_bwd_v<T, TW, W, 1>(a, st);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_gather_conv1d_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
