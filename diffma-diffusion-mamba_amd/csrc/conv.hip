@@ -15,6 +15,7 @@
 namespace dm {
 
 constexpr int CONV_CH = 14;   // time steps per wave chunk (196 = 14*14)
+constexpr int CONV_BWD_WAVES = 7;   // backward: waves (= consecutive chunks) per workgroup, their dw/db partials are summed in LDS
 
 // VEC channels per lane: 16-bit I/O moves 2 channels per 32-bit access (half the memory instructions per byte;
 // the 16-bit version is issue-bound: 3.8 vs 5.7 TB/s-equivalent measured against fp32 I/O).
@@ -112,10 +113,12 @@ __global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) 
 // dw[j] += g[m]*x[idx[m-(W-1)+j]];  db += g[m].   A chunk needs pre/g on [lbeg, lbeg+CH+W-1) and x
 // on [lbeg-(W-1), lbeg+CH+W-1).
 template <typename T, typename TW, int W, bool SILU, int VEC>
-__global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * CONV_BWD_WAVES) void conv_bwd_kernel(const dm_conv_bwd_args p) {
+    __shared__ float part_lds[CONV_BWD_WAVES][(W + 1) * VEC][WAVE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: keeps the chunk's row arithmetic scalar
     const int d0 = blockIdx.x * WAVE * VEC;
-    const int c = blockIdx.y;
+    const int c = blockIdx.y * CONV_BWD_WAVES + wave;          // chunks past the end of the sequence only contribute zeros
     const int s = blockIdx.z;
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
@@ -192,6 +195,7 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) 
             g[j][v] = gv;
         }
     }
+    // ---- dx rows, scattered back to token order --------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < CONV_CH; ++j) {
         const int m = lbeg + j;
@@ -207,13 +211,29 @@ __global__ __launch_bounds__(64) void conv_bwd_kernel(const dm_conv_bwd_args p) 
             if (active) vio<T, VEC>::st(dxp + (int64_t)r * p.dx_sl, acc);
         }
     }
-    if (active) {
-        float* dwp = p.dw_partial + (((int64_t)s * p.nchunk + c) * p.dim + d) * W;
+    // parameter gradients: sum the workgroup's chunks in LDS, one partial row per (sequence, workgroup).  The barrier only
+    // orders LDS (lgkmcnt): __syncthreads() would also wait for the dx stores above to be acknowledged.
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) {
+    for (int v = 0; v < VEC; ++v) {
 #pragma unroll
-            for (int k = 0; k < W; ++k) dwp[v * W + k] = dw[k][v];
-            if (p.db_partial) p.db_partial[((int64_t)s * p.nchunk + c) * p.dim + d + v] = db[v];
+        for (int k = 0; k < W; ++k) part_lds[wave][v * W + k][lane] = dw[k][v];
+        part_lds[wave][W * VEC + v][lane] = db[v];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (wave == 0 && active) {
+        float acc[(W + 1) * VEC];
+#pragma unroll
+        for (int i = 0; i < (W + 1) * VEC; ++i) {
+            acc[i] = 0.0f;
+#pragma unroll
+            for (int wv = 0; wv < CONV_BWD_WAVES; ++wv) acc[i] += part_lds[wv][i][lane];
+        }
+        float* dwp = p.dw_partial + (((int64_t)s * p.nchunk + blockIdx.y) * p.dim + d) * W;
+#pragma unroll
+        for (int i = 0; i < W * VEC; ++i) dwp[i] = acc[i];
+        if (p.db_partial) {
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) p.db_partial[((int64_t)s * p.nchunk + blockIdx.y) * p.dim + d + v] = acc[W * VEC + v];
         }
     }
 }
@@ -249,8 +269,7 @@ static int launch_conv_fwd(const dm_conv_fwd_args& a, hipStream_t st) {
 
 template <typename T, typename TW, int W, int VEC>
 static void launch_conv_bwd_v(const dm_conv_bwd_args& a, hipStream_t st) {
-    const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
-    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), nchunk, a.ndir * a.batch), block(WAVE);
+    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), a.nchunk, a.ndir * a.batch), block(WAVE * CONV_BWD_WAVES);
     if (a.flags & DM_FLAG_SILU)
         hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, a);
     else
@@ -296,7 +315,11 @@ static int conv_bwd_t(const dm_conv_bwd_args& a, hipStream_t st) {
 
 }  // namespace dm
 
-extern "C" int dm_conv_nchunk(int seqlen) { return (seqlen + dm::CONV_CH - 1) / dm::CONV_CH; }
+// number of dw/db partial rows per sequence the backward writes (one per workgroup of CONV_BWD_WAVES chunks)
+extern "C" int dm_conv_nchunk(int seqlen) {
+    const int chunks = (seqlen + dm::CONV_CH - 1) / dm::CONV_CH;
+    return (chunks + dm::CONV_BWD_WAVES - 1) / dm::CONV_BWD_WAVES;
+}
 
 extern "C" int dm_gather_conv1d_fwd(const dm_conv_fwd_args* args, void* stream) {
     using namespace dm;

@@ -173,7 +173,8 @@ int dm_gather_conv1d_fwd(const dm_conv_fwd_args *args, void *stream);
  *   dx_dir[dir][b][ idx[dir][m] ][d] = sum_j w[d][j] * g[dir][b][m+(W-1)-j][d],   g = dout * act'(pre)
  * i.e. the gradient of every direction is written back in TOKEN order (the scatter through idx is the
  * adjoint of the gather); the caller sums the ndir slabs with dm_token_merge.
- *   dw_partial: [ndir*batch][nchunk][dim][width] fp32, db_partial: [ndir*batch][nchunk][dim] fp32.
+ *   dw_partial: [ndir*batch][nchunk][dim][width] fp32, db_partial: [ndir*batch][nchunk][dim] fp32: one partial row
+ *   per workgroup (a run of consecutive time chunks of one sequence); nchunk = dm_conv_nchunk(seqlen).
  */
 typedef struct {
     int32_t batch, dim, seqlen, width, ndir;
