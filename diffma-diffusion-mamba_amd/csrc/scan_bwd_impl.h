@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     const rsrc_t r_u = make_rsrc((const T*)p.u + (int64_t)s * p.u_ss);
     const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
     const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
-    const rsrc_t r_g = make_rsrc((const T*)p.dout + (int64_t)(IDX ? sb : s) * p.do_ss);
+    const rsrc_t r_g = make_rsrc((const T*)p.dout + (int64_t)((IDX && !(p.flags & DM_FLAG_DOUT_PER_SEQ)) ? sb : s) * p.do_ss);
     const rsrc_t r_du = make_rsrc((T*)p.du + (int64_t)s * p.du_ss);
     const rsrc_t r_ddt = make_rsrc((T*)p.ddelta + (int64_t)s * p.ddt_ss);
     const rsrc_t r_dz = make_rsrc(HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);

@@ -306,19 +306,16 @@ class _IndexedScanFn(torch.autograd.Function):
         u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, ckpt = ctx.saved_tensors
         ndir, Bsz = scan_index.shape[0], ctx.Bsz
         S, L, Dm = u.shape
-        # dy is per direction here (the merge happens after the norm), so it is read like a plain [S, L, Dm] tensor whose
-        # rows are in TOKEN order: gather rows through the table but index the batch by the sequence (batch_per_dir = 0 path
-        # is not usable), hence one kernel call per direction slab is avoided by viewing dy as ndir*B sequences.
+        # dy is per direction here (the gated RMSNorm sits between the scan and the merge): the kernel gathers its rows through
+        # the same table as the forward's scatter, indexed by sequence instead of by batch (DM_FLAG_DOUT_PER_SEQ); z is
+        # gathered in the kernel and dz comes back per direction in token order, so the 3 slabs only need the merge sum.
         dy = dy.reshape(S, L, Dm).contiguous()
         if dy.dtype != u.dtype:
             dy = dy.to(u.dtype)
-        dy_scan = torch.stack([dy.view(ndir, Bsz, L, Dm)[k][:, scan_index[k].long(), :] for k in range(ndir)]).reshape(S, L, Dm)
-        zg = torch.stack([z[:, scan_index[k].long(), :] for k in range(ndir)]).reshape(S, L, Dm)
-        du, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(u, delta, A, Bm, Cm, D, zg, dt_bias, dy_scan, ckpt, True)
-        dz = torch.zeros_like(z, dtype=torch.float32)
-        dzs = dzs.view(ndir, Bsz, L, Dm)
-        for k in range(ndir):
-            dz.index_add_(1, scan_index[k].long(), dzs[k].float())
+        du, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(u, delta, A, Bm, Cm, D, z, dt_bias, dy, ckpt, True,
+                                                                  z_row_index=scan_index, out_row_index=scan_index,
+                                                                  batch_per_dir=Bsz, dout_per_seq=True)
+        dz = hip_ops.token_merge(dzs.view(ndir, Bsz, L, Dm))
         return (du, ddelta, dA.to(A.dtype), dB.to(Bm.dtype), dC.to(Cm.dtype), dD.to(D.dtype), dz.to(z.dtype), dbias.to(dt_bias.dtype),
                 None, None)
 

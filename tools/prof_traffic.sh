@@ -21,4 +21,5 @@ for dt in ("bf16", "fp32"):
             res.setdefault(dt, {}).setdefault(r[0][:90], {})[cname] = dict(avg=r[1], n=r[2], dur_ns=r[3])
 print(json.dumps(res, indent=1))
 open("$OUT/traffic.json", "w").write(json.dumps(res, indent=1))
+open("$R/gpurun_out/traffic.json", "w").write(json.dumps(res, indent=1))
 PY
