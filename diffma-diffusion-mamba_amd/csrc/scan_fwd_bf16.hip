@@ -1,5 +1,5 @@
 // scan_fwd: bf16 I/O instantiations (split per dtype so the library builds in parallel)
-#include "scan_fwd_impl.h"
+#include "scan_fwd_chunked.h"
 namespace dm {
-int scan_fwd_bf16(const dm_scan_fwd_args& a, hipStream_t st) { return dispatch_bc<bf16_t>(a, st); }
+int scan_fwd_bf16(const dm_scan_fwd_args& a, hipStream_t st) { return dispatch_fwd<bf16_t>(a, st); }
 }  // namespace dm

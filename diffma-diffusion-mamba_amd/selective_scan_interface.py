@@ -39,7 +39,7 @@ def _bc_token_major(Bm: torch.Tensor):
 
 class _SelectiveScanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, return_last_state):
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, return_last_state, grad_on=True):
         ut, dt = _to_token_major(u), _to_token_major(delta)
         zt = _to_token_major(z) if z is not None else None
         if dt.dtype != ut.dtype:
@@ -54,7 +54,8 @@ class _SelectiveScanFn(torch.autograd.Function):
             Ct = Ct.to(Bt.dtype)
         S, L, Dm = ut.shape
         N = A.shape[1]
-        need_grad = any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
+        # grad_on = the caller's grad mode (inside forward() it is always off): no checkpoints under torch.no_grad()
+        need_grad = grad_on and any(t is not None and t.requires_grad for t in (u, delta, A, Bm, Cm, D, z, delta_bias))
         ckpt = None
         if need_grad:
             ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, ut.dtype, ut.device)
@@ -91,7 +92,7 @@ class _SelectiveScanFn(torch.autograd.Function):
             dCm = dCm[:, None]
         return (cm(du), cm(ddelta), dA.to(A.dtype), dBm, dCm,
                 dD.to(D.dtype) if ctx.has_D else None, cm(dz) if ctx.has_z else None,
-                dbias.to(delta_bias.dtype) if ctx.has_bias else None, None, None)
+                dbias.to(delta_bias.dtype) if ctx.has_bias else None, None, None, None)
 
 
 def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
@@ -105,7 +106,7 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
         raise NotImplementedError("complex A is not supported (DiffMa uses the real S4D-real init, block/mamba.py:304-310)")
     if B.dim() not in (3, 4) or C.dim() not in (3, 4):
         raise NotImplementedError("only input-dependent B/C are supported (the only mode DiffMa uses)")
-    return _SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+    return _SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state, torch.is_grad_enabled())
 
 
 class _CausalConv1dFn(torch.autograd.Function):
@@ -198,7 +199,7 @@ class _SpiralSSMFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index):
+    def forward(ctx, xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, grad_on=True):
         Bsz, L, D2 = xz.shape
         Din = D2 // 2
         ndir = scan_index.shape[0]
@@ -206,7 +207,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         N = A.shape[1]
         dt_ = xz.dtype
         x_view, z_view = xz[..., :Din], xz[..., Din:]
-        need_grad = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8])
+        need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
         xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
         x_dbl = F.linear(xc.view(-1, Din), Wx.to(dt_))                         # [ndir*B*L, R+2N]
         delta = F.linear(x_dbl[:, :R], Wdt.to(dt_)).view(ndir * Bsz, L, Din)
@@ -255,7 +256,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
         hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
         return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
-                dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None)
+                dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None, None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -289,10 +290,10 @@ def gather_conv1d(x, conv_weight, conv_bias, scan_index):
 
 class _IndexedScanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
+    def forward(ctx, u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz, grad_on=True):
         S, L, Dm = u.shape
         N = A.shape[1]
-        need_grad = any(ctx.needs_input_grad[:8])
+        need_grad = grad_on and any(ctx.needs_input_grad[:8])
         ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, u.dtype, u.device) if need_grad else None
         A = A.contiguous()
         y = hip_ops.scan_fwd(u, delta, A, Bm, Cm, D, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
@@ -317,7 +318,7 @@ class _IndexedScanFn(torch.autograd.Function):
                                                                   batch_per_dir=Bsz, dout_per_seq=True)
         dz = hip_ops.token_merge(dzs.view(ndir, Bsz, L, Dm))
         return (du, ddelta, dA.to(A.dtype), dB.to(Bm.dtype), dC.to(Cm.dtype), dD.to(D.dtype), dz.to(z.dtype), dbias.to(dt_bias.dtype),
-                None, None)
+                None, None, None)
 
 
 def indexed_scan(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
@@ -329,7 +330,8 @@ def indexed_scan(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
             delta = delta.to(u.dtype)
         if z is None:
             raise NotImplementedError("norm_before_gate=True (ungated scan) is not wired; DiffMa uses norm_before_gate=False")
-        return _IndexedScanFn.apply(u, delta.contiguous(), A.float(), Bm, Cm, D.float(), z, dt_bias.float(), scan_index, Bsz)
+        return _IndexedScanFn.apply(u, delta.contiguous(), A.float(), Bm, Cm, D.float(), z, dt_bias.float(), scan_index, Bsz,
+                                    torch.is_grad_enabled())
 
 
 class _MergeFn(torch.autograd.Function):
@@ -394,7 +396,7 @@ def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, sca
     """
     with torch.autocast(device_type="cuda", enabled=False):
         return _SpiralSSMFn.apply(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b.float(), A.float(), Dskip.float(),
-                                  scan_index)
+                                  scan_index, torch.is_grad_enabled())
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,

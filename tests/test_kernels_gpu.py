@@ -54,6 +54,39 @@ def test_scan_fwd_matches_oracle(gpu, dtype, S, L, Dm):
     torch.testing.assert_close(last.cpu().double().permute(0, 2, 1), ref_last, rtol=1e-4, atol=1e-5 * max(1.0, ref_last.abs().max().item()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("L,Dm,with_z", [(196, 128, True), (100, 200, True), (57, 64, False), (183, 128, True)])
+def test_scan_fwd_chunk_parallel_variant(gpu, dtype, L, Dm, with_z):
+    """Small launches without checkpoints take the chunk-parallel kernel (csrc/scan_fwd_chunked.h: 14 waves x 14 steps,
+    two passes); ragged L / dim, row-index gather + scatter with 3 directions sharing one z."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import selective_scan_ref
+
+    Bsz, ndir, N = 2, 3, 16
+    S = Bsz * ndir
+    host, d = _inputs(S, L, Dm, N, dtype, seed=L + Dm, dev=gpu, with_z=False)
+    g = torch.Generator().manual_seed(9)
+    zsrc = torch.randn(Bsz, L, Dm, generator=g).to(dtype) if with_z else None
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    operms = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+    if with_z:
+        out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zsrc.to(gpu), d["bias"], True,
+                               z_row_index=perms.to(gpu), out_row_index=operms.to(gpu), batch_per_dir=Bsz)
+    else:
+        out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], None, d["bias"], True)
+    torch.cuda.synchronize()
+    out = out.float().cpu()
+    rtol, atol = TOL[dtype]
+    for s in range(S):
+        k, b = divmod(s, Bsz)
+        cm = lambda t: t[s:s + 1].float().permute(0, 2, 1).double()
+        zz = zsrc[b][perms[k].long()].float().T[None].double() if with_z else None
+        ref = selective_scan_ref(cm(host["u"]), cm(host["delta"]), host["A"].double(), cm(host["B"]), cm(host["C"]),
+                                 host["D"].double(), z=zz, delta_bias=host["bias"].double(), delta_softplus=True)[0].T
+        got = out[s][operms[k].long()] if with_z else out[s]
+        torch.testing.assert_close(got.double(), ref, rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("softplus,with_z", [(False, True), (True, False), (False, False)])
 def test_scan_fwd_flags(gpu, softplus, with_z):
     from diffma_amd import hip_ops

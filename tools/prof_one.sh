@@ -8,6 +8,6 @@ python - <<PY
 import sqlite3, glob
 db = glob.glob("$OUT/trace/*.db")[0]
 cur = sqlite3.connect(db).cursor()
-for n, c, t, a, p in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 8"):
+for n, c, t, a, p in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 14"):
     print(f"{p:6.2f}% calls={c:5d} avg_us={a:9.1f}  {n[:100]}")
 PY
