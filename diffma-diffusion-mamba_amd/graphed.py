@@ -15,10 +15,22 @@ class GraphedDenoiser:
     """Callable with the model's signature `(x, t, y=, y2=, w=)`; replays a captured graph.
 
     The conditioning tensors y, y2, w are fixed for a whole sampling run: they are copied into the static
-    buffers only when their storage changes."""
+    buffers only when their storage changes.
 
-    def __init__(self, model, x, t, y, y2, w, autocast_dtype=None, warmup=3):
+    With an autocast dtype the graph runs on a SNAPSHOT of the model whose nn.Linear weight matrices are stored in
+    that dtype (autocast would otherwise re-cast every fp32 weight inside the captured graph on every replay: ~180
+    cast kernels per step).  Everything autocast keeps in fp32 (norm weights, biases, A_log, D, the residual stream)
+    stays fp32, so the outputs are those of the autocast model.  Pass `snapshot_weights=False` to capture the live
+    model instead (e.g. when its weights keep changing)."""
+
+    def __init__(self, model, x, t, y, y2, w, autocast_dtype=None, warmup=3, snapshot_weights=True):
         assert x.is_cuda, "graph capture needs a ROCm device"
+        if autocast_dtype is not None and snapshot_weights:
+            import copy
+            model = copy.deepcopy(model).eval()
+            for m in model.modules():
+                if isinstance(m, torch.nn.Linear):
+                    m.weight.data = m.weight.data.to(autocast_dtype)
         self.model = model
         self.amp = autocast_dtype
         self.sx, self.st = x.clone(), t.clone()

@@ -76,7 +76,14 @@ class Mamba(nn.Module):
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
-        A = -torch.exp(self.A_log.float())
+        if torch.is_grad_enabled():
+            A = -torch.exp(self.A_log.float())
+        else:                                        # inference: A only changes when A_log does (two tiny kernels per call otherwise)
+            cache = getattr(self, "_A_cache", None)
+            if cache is None or cache[0] != self.A_log._version or cache[1].device != self.A_log.device:
+                cache = (self.A_log._version, -torch.exp(self.A_log.detach().float()))
+                self._A_cache = cache
+            A = cache[1]
         y = spiral_ssm(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                        self.dt_proj.bias, A, self.D, self.scan_index)
         return linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)
