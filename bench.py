@@ -45,6 +45,7 @@ def parse():
                     help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): recorded table / library default / time unseen shapes")
     ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
+    ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
     ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
     return ap.parse_args()
 
@@ -161,7 +162,7 @@ def main():
             return loss
     else:
         model.eval()
-        sdiff = create_diffusion("250")
+        sdiff = create_diffusion("250" if args.sampler == "ddpm250" else "ddim50")
         state = {"x": batch["z"].clone(), "i": sdiff.num_timesteps - 1}
         denoiser = model.forward
         if args.graph:
@@ -172,7 +173,7 @@ def main():
         def step():
             t = torch.full((B,), state["i"], device=dev, dtype=torch.long)
             with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None and not args.graph):
-                out = sdiff.p_sample(denoiser, state["x"], t, clip_denoised=False, model_kwargs=kw)
+                out = (sdiff.p_sample if args.sampler == "ddpm250" else sdiff.ddim_sample)(denoiser, state["x"], t, clip_denoised=False, model_kwargs=kw)
             state["x"] = out["sample"].float()
             state["i"] = state["i"] - 1 if state["i"] > 0 else sdiff.num_timesteps - 1
             return out["sample"]
@@ -245,7 +246,7 @@ def main():
         except (OSError, KeyError, ValueError):
             pass
         res = {
-            "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else '250-step DDPM sampling'}; samples*steps/s)",
+            "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else ('250-step DDPM sampling' if args.sampler == 'ddpm250' else '50-step DDIM sampling')}; samples*steps/s)",
             "value": round(args.steps * B * world / elapsed, 3),
             "unit": "samples*steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,7 +255,7 @@ def main():
             "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
             "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
             "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" if args.mode == "train"
-                       else f"{args.model} p_sample step (250-step respaced DDPM), batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
+                       else f"{args.model} {'p_sample step (250-step respaced DDPM)' if args.sampler == 'ddpm250' else 'ddim_sample step (50-step DDIM)'}, batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
