@@ -81,6 +81,7 @@ dm_conv_bwd_args = _make_struct("dm_conv_bwd_args")
 dm_merge_args = _make_struct("dm_merge_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
+dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 
 _lib = None
 _lock = threading.Lock()

@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args,
                    dm_conv_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -373,3 +373,46 @@ def blend_bwd(g, xs, ws, a_row, gate):
     a.g, a.dxs, a.dws, a.da, a.dgate_part = _ptr(g), _ptr(dxs), _ptr(dws), _ptr(da), _ptr(part)
     _launch("dm_blend_bwd", a, g, Bsz * L * C * (g.element_size() + 4 * xs.element_size()))
     return dxs, dws, da, part.sum(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Mamba-2 epilogue: gated RMSNorm of every direction slab + 3-way merge (csrc/rmsnorm.hip)
+# ------------------------------------------------------------------------------------------------
+def _rms_args(y, weight, eps):
+    K, Bsz, L, C = y.shape
+    assert y.stride(3) == 1 and y.stride(1) == L * y.stride(2), "slabs must be [K, B, L, C] with contiguous rows"
+    a = dm_rmsnorm_merge_args()
+    a.nslab, a.C, a.rows = K, C, Bsz * L
+    a.io_dtype = dtype_code(y)
+    a.eps = float(eps)
+    a.y, a.weight = _ptr(y), _ptr(weight)
+    a.y_ss, a.y_sr = y.stride(0), y.stride(2)
+    return a, K, Bsz, L, C
+
+
+def rmsnorm_merge_fwd(y, weight, eps):
+    """y [K, B, L, C] (token order, gated) -> (out [B, L, C] = w * sum_k rmsnorm(y_k), rstd [K, B*L] fp32)."""
+    weight = _f32c(weight)
+    _require_gpu(y, weight)
+    a, K, Bsz, L, C = _rms_args(y, weight, eps)
+    out = torch.empty((Bsz, L, C), dtype=y.dtype, device=y.device)
+    rstd = torch.empty((K, Bsz * L), dtype=torch.float32, device=y.device)
+    a.out, a.rstd, a.out_sr = _ptr(out), _ptr(rstd), C
+    _launch("dm_rmsnorm_merge_fwd", a, y, (K + 1) * Bsz * L * C * y.element_size())
+    return out, rstd
+
+
+def rmsnorm_merge_bwd(y, weight, eps, rstd, dout):
+    """Returns (dy [K, B, L, C], dweight [C] fp32)."""
+    weight = _f32c(weight)
+    _require_gpu(y, weight, dout)
+    a, K, Bsz, L, C = _rms_args(y, weight, eps)
+    dout = dout.contiguous()
+    dy = torch.empty((K, Bsz, L, C), dtype=y.dtype, device=y.device)
+    rpb = _lib.load().dm_rmsnorm_merge_rows_per_block()
+    nblk = (Bsz * L + rpb - 1) // rpb
+    part = torch.empty((nblk, C), dtype=torch.float32, device=y.device)
+    a.rstd, a.dout, a.dy, a.dw_part = _ptr(rstd), _ptr(dout), _ptr(dy), _ptr(part)
+    a.dout_sr, a.dy_ss, a.dy_sr = C, dy.stride(0), C
+    _launch("dm_rmsnorm_merge_bwd", a, y, (2 * K + 1) * Bsz * L * C * y.element_size())
+    return dy, part.sum(0)

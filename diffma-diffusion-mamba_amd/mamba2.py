@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import gather_conv1d, indexed_scan, linear_splitk, merge_slabs
+from .selective_scan_interface import gather_conv1d, indexed_scan, linear_splitk, rmsnorm_merge
 
 
 class RMSNorm(nn.Module):
@@ -107,6 +107,6 @@ class Mamba2(nn.Module):
         Dskip = self.D.float().repeat_interleave(P)
         dt_bias = self.dt_bias.float().repeat_interleave(P)
         y = indexed_scan(x, delta, A, Bm, Cm, Dskip, z, dt_bias, self.scan_index, Bsz)      # [ndir, B, L, Din] token order, gated by silu(z)
-        y = self.norm(y)                                                          # row-wise: commutes with the token permutation
-        y = merge_slabs(y)                                                        # [B, L, Din]
+        y = rmsnorm_merge(y, self.norm.weight, self.norm.eps)                     # gated RMSNorm per slab (row-wise: commutes with the
+                                                                                  # token permutation) + 3-way merge -> [B, L, Din]
         return linear_splitk(y.to(zxbcdt.dtype), self.out_proj.weight, self.out_proj.bias)

@@ -345,6 +345,31 @@ class _MergeFn(torch.autograd.Function):
         return dy.unsqueeze(0).expand(ctx.k, *dy.shape)
 
 
+class _RmsMergeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, slabs, weight, eps):
+        slabs = slabs.contiguous()
+        out, rstd = hip_ops.rmsnorm_merge_fwd(slabs, weight, eps)
+        ctx.save_for_backward(slabs, weight, rstd)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        slabs, weight, rstd = ctx.saved_tensors
+        if dout.dtype != slabs.dtype:
+            dout = dout.to(slabs.dtype)
+        dy, dw = hip_ops.rmsnorm_merge_bwd(slabs, weight, ctx.eps, rstd, dout)
+        return dy, dw.to(weight.dtype), None
+
+
+def rmsnorm_merge(slabs, weight, eps):
+    """[K, B, L, C] gated scan outputs (token order) -> weight * sum_k RMSNorm(slab_k): the Mamba-2 gated RMSNorm
+    (norm_before_gate = False, block/mamba2.py:349) fused with the 3-way CrossMerge."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _RmsMergeFn.apply(slabs, weight, eps)
+
+
 def merge_slabs(slabs):
     """[K, B, L, Dm] -> sum over K (CrossMerge after the rows are already in token order)."""
     return _MergeFn.apply(slabs)

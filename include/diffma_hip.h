@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 6
+#define DM_ABI_VERSION 7
 
 typedef enum {
     DM_OK = 0,
@@ -265,6 +265,33 @@ typedef struct {
 
 int dm_blend_fwd(const dm_blend_args *args, void *stream);
 int dm_blend_bwd(const dm_blend_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Gated-RMSNorm epilogue of the Mamba-2 mixer fused with the 3-way CrossMerge (block/mamba2.py:349,402-403,
+ * norm_before_gate = False; the gate is applied by the scan):
+ *     out[r][:] = weight[:] * sum_k  y_k[r][:] * rsqrt(mean(y_k[r][:]^2) + eps)
+ * y: [nslab][rows][C] slabs already in token order; rstd: [nslab][rows] fp32 (written by fwd, read by bwd).
+ * bwd: dy [nslab][rows][C]; dw_part: [ceil(rows / dm_rmsnorm_merge_rows_per_block())][C] fp32 partial rows.
+ * C % 4 == 0, C <= 4096; row/slab strides in elements (multiples of 4); 16-byte aligned tensors.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nslab, C;
+    int64_t rows;
+    int32_t io_dtype;                           /* y, out, dout, dy                                          */
+    float eps;
+    const void *y;
+    const float *weight;                        /* [C] fp32                                                  */
+    void *out;                                  /* fwd: [rows][C]                                            */
+    float *rstd;
+    const void *dout;                           /* bwd: [rows][C]                                            */
+    void *dy;                                   /* bwd                                                       */
+    float *dw_part;                             /* bwd                                                       */
+    int64_t y_ss, y_sr, out_sr, dout_sr, dy_ss, dy_sr;
+} dm_rmsnorm_merge_args;
+
+int dm_rmsnorm_merge_fwd(const dm_rmsnorm_merge_args *args, void *stream);
+int dm_rmsnorm_merge_bwd(const dm_rmsnorm_merge_args *args, void *stream);
+int dm_rmsnorm_merge_rows_per_block(void);
 
 /* Library introspection. */
 int dm_abi_version(void);

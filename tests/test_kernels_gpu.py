@@ -318,3 +318,29 @@ def test_gather_conv_bwd_matches_oracle_autograd(gpu, Bsz, L, Dm, W):
     sc = max(1.0, wd.grad.abs().max().item())
     torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=1e-4, atol=2e-5 * sc)
     torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=1e-4, atol=2e-5 * sc)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,rows", [(1024, 70), (2304, 33), (200, 5)])
+def test_rmsnorm_merge_matches_torch(gpu, dtype, C, rows):
+    """Mamba-2 epilogue (csrc/rmsnorm.hip): w * sum_k RMSNorm(y_k), forward and backward vs fp64 autograd of the formula the
+    reference's gated RMSNorm applies per direction (block/mamba2.py:349; gate already applied by the scan)."""
+    from diffma_amd import hip_ops
+
+    K, Bsz, eps = 3, 1, 1e-5
+    g = torch.Generator().manual_seed(C + rows)
+    y = torch.randn(K, Bsz, rows, C, generator=g).to(dtype)
+    w = torch.randn(C, generator=g)
+    dout = torch.randn(Bsz, rows, C, generator=g).to(dtype)
+    out, rstd = hip_ops.rmsnorm_merge_fwd(y.to(gpu), w.to(gpu), eps)
+    dy, dw = hip_ops.rmsnorm_merge_bwd(y.to(gpu), w.to(gpu), eps, rstd, dout.to(gpu))
+    torch.cuda.synchronize()
+    yr = y.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    ref = (yr * torch.rsqrt(yr.pow(2).mean(-1, keepdim=True) + eps)).sum(0) * wr
+    ref.backward(dout.double())
+    rtol, atol = TOL[dtype]
+    sc = lambda t: atol * max(1.0, t.abs().max().item())
+    torch.testing.assert_close(out.float().cpu().double(), ref.detach(), rtol=rtol, atol=sc(ref.detach()))
+    torch.testing.assert_close(dy.float().cpu().double(), yr.grad, rtol=rtol, atol=sc(yr.grad))
+    torch.testing.assert_close(dw.cpu().double(), wr.grad, rtol=max(rtol, 1e-3), atol=sc(wr.grad))
