@@ -152,7 +152,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
 
 def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
-             ngroups=1, dz_out=None, dout_per_seq=False):
+             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None):
     """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
     already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
     z_row_index is given)."""
@@ -165,7 +165,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     nw = (Dm + gc - 1) // gc
     dev = u.device
     A32, D32, b32 = _f32c(A), _f32c(D), _f32c(delta_bias)
-    du = torch.empty_like(u)
+    du = du_out if du_out is not None else torch.empty_like(u)      # du_out: a [S, L, Dm] view with channel stride 1
     ddelta = torch.empty((S, L, Dm), dtype=u.dtype, device=dev)
     dz = None
     if z is not None:

@@ -19,7 +19,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import gather_conv1d, indexed_scan, linear_splitk, rmsnorm_merge
+from .selective_scan_interface import linear_splitk, spiral_ssd
 
 
 class RMSNorm(nn.Module):
@@ -83,6 +83,7 @@ class Mamba2(nn.Module):
         L = len(self.token_list)
         idx = torch.tensor([list(range(L)), self.token_list, self.token_list_reversal], dtype=torch.int32) if L else torch.zeros((3, 0), dtype=torch.int32)
         self.register_buffer("scan_index", idx, persistent=False)
+        self.register_buffer("scan_index_inv", torch.argsort(idx.long(), dim=1).to(torch.int32), persistent=False)
 
     def forward(self, u, scan_type="spiral", seqlen=None, seq_idx=None, inference_params=None):
         """u: (B, L, d_model) -> (B, L, d_model)."""
@@ -96,17 +97,7 @@ class Mamba2(nn.Module):
         Din, N, H, P = self.d_inner, self.d_state, self.nheads, self.headdim
         ndir = self.scan_index.shape[0]
         zxbcdt = linear_splitk(u, self.in_proj.weight, self.in_proj.bias)             # [B, L, 2*Din + 2N + H], token-major
-        z = zxbcdt[..., :Din]
-        xBC = gather_conv1d(zxbcdt[..., Din:2 * Din + 2 * N], self.conv1d.weight, self.conv1d.bias, self.scan_index)   # [ndir*B, L, Din+2N]
-        x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
-        # dt is produced before the token gather: gather its H columns per direction, then broadcast head -> channels
-        dt = zxbcdt[..., 2 * Din + 2 * N:]
-        dt = torch.stack([dt[:, self.scan_index[k].long(), :] for k in range(ndir)], dim=0).reshape(ndir * Bsz, L, H)
-        delta = dt.repeat_interleave(P, dim=-1)                                  # [ndir*B, L, Din]
-        A = (-torch.exp(self.A_log.float())).repeat_interleave(P)[:, None].expand(Din, N)
-        Dskip = self.D.float().repeat_interleave(P)
-        dt_bias = self.dt_bias.float().repeat_interleave(P)
-        y = indexed_scan(x, delta, A, Bm, Cm, Dskip, z, dt_bias, self.scan_index, Bsz)      # [ndir, B, L, Din] token order, gated by silu(z)
-        y = rmsnorm_merge(y, self.norm.weight, self.norm.eps)                     # gated RMSNorm per slab (row-wise: commutes with the
-                                                                                  # token permutation) + 3-way merge -> [B, L, Din]
+        A = -torch.exp(self.A_log.float())                                        # [H]
+        y = spiral_ssd(zxbcdt, self.conv1d.weight, self.conv1d.bias, self.dt_bias, A, self.D, self.norm.weight, self.norm.eps,
+                       self.scan_index, self.scan_index_inv, Din, N)                 # [B, L, Din]: gated, normalised, merged
         return linear_splitk(y.to(zxbcdt.dtype), self.out_proj.weight, self.out_proj.bias)

@@ -321,6 +321,79 @@ class _IndexedScanFn(torch.autograd.Function):
                 None, None, None)
 
 
+class _SpiralSSDFn(torch.autograd.Function):
+    """The Mamba-2 mixer between in_proj and out_proj as ONE autograd node: zxbcdt [B, L, 2*Din + 2N + H] (token-major
+    in_proj output, column blocks [z | x | B | C | dt], block/mamba2.py:380-400) -> gated, RMS-normalised, merged y [B, L, Din].
+    The backward assembles d(zxbcdt) in place from the kernels' outputs (no slice/cat/index autograd nodes, no zero fills)."""
+
+    @staticmethod
+    def forward(ctx, zxbcdt, conv_w, conv_b, dt_bias_h, A_h, D_h, norm_w, eps, scan_index, scan_index_inv, Din, N, grad_on=True):
+        Bsz, L, _ = zxbcdt.shape
+        H = A_h.shape[0]
+        P = Din // H
+        ndir = scan_index.shape[0]
+        S, Cx = ndir * Bsz, Din + 2 * N
+        z, xbc_in, dt_tok = zxbcdt[..., :Din], zxbcdt[..., Din:Din + Cx], zxbcdt[..., Din + Cx:]
+        xBC = hip_ops.gather_conv1d_fwd(xbc_in, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)        # [S, L, Cx]
+        x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
+        # dt is produced per token and per head: gather its rows per direction, broadcast head -> channels
+        dt_g = torch.stack([dt_tok[:, scan_index[k].long()] for k in range(ndir)])                                 # [ndir, B, L, H]
+        delta = dt_g.reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din)
+        A = A_h.float().repeat_interleave(P)[:, None].expand(Din, N).contiguous()
+        Dskip = D_h.float().repeat_interleave(P)
+        dt_bias = dt_bias_h.float().repeat_interleave(P)
+        need_grad = grad_on and any(ctx.needs_input_grad[:7])
+        ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, zxbcdt.dtype, zxbcdt.device) if need_grad else None
+        ydir = hip_ops.scan_fwd(x, delta, A, Bm, Cm, Dskip, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
+                                batch_per_dir=Bsz, ckpt=ckpt)                                                     # token order, gated
+        out, rstd = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+        ctx.save_for_backward(zxbcdt, conv_w, conv_b, xBC, delta, A, Dskip, dt_bias, ckpt, ydir, rstd, norm_w, scan_index, scan_index_inv)
+        ctx.meta = (Din, N, H, P, eps, dt_bias_h.dtype, A_h.dtype, D_h.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        zxbcdt, conv_w, conv_b, xBC, delta, A, Dskip, dt_bias, ckpt, ydir, rstd, norm_w, scan_index, scan_index_inv = ctx.saved_tensors
+        Din, N, H, P, eps, bias_dt, A_dt, D_dt = ctx.meta
+        Bsz, L, _ = zxbcdt.shape
+        ndir = scan_index.shape[0]
+        S, Cx = ndir * Bsz, Din + 2 * N
+        dt_ = zxbcdt.dtype
+        if dout.dtype != dt_:
+            dout = dout.to(dt_)
+        dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
+        dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
+        x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
+        _, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(
+            x, delta, A, Bm, Cm, Dskip, zxbcdt[..., :Din], dt_bias, dyd.view(S, L, Din), ckpt, True, z_row_index=scan_index,
+            out_row_index=scan_index, batch_per_dir=Bsz, dout_per_seq=True, du_out=dxBC[..., :Din])
+        dxBC[..., Din:Din + N].copy_(dB)
+        dxBC[..., Din + N:].copy_(dC)
+        dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(zxbcdt[..., Din:Din + Cx], conv_w, conv_b, dxBC, row_index=scan_index,
+                                                               ndir=ndir, silu=True)                              # token order
+        dzx = torch.empty_like(zxbcdt)
+        hip_ops.token_merge(dzs.view(ndir, Bsz, L, Din), out=dzx[..., :Din])
+        hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Cx), out=dzx[..., Din:Din + Cx])
+        # d(dt): sum the head's channels, put every direction back in token order (adjoint of the row gather), add the directions
+        ddt = ddelta.view(S * L * H, P).float().sum(-1).view(ndir, Bsz, L, H)
+        ddt_tok = ddt[0][:, scan_index_inv[0].long()]
+        for k in range(1, ndir):
+            ddt_tok = ddt_tok + ddt[k][:, scan_index_inv[k].long()]
+        dzx[..., Din + Cx:].copy_(ddt_tok)
+        dA_h = dA.view(H, P * N).sum(-1)
+        dD_h = dD.view(H, P).sum(-1)
+        dbias_h = dbias.view(H, P).sum(-1)
+        return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
+                dbias_h.to(bias_dt), dA_h.to(A_dt), dD_h.to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
+
+
+def spiral_ssd(zxbcdt, conv_w, conv_b, dt_bias, A, D, norm_w, eps, scan_index, scan_index_inv, d_inner, d_state):
+    """Fused core of the Mamba-2 'spiral' mixer (see _SpiralSSDFn).  A = -exp(A_log) [H], dt_bias [H], D [H]."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _SpiralSSDFn.apply(zxbcdt, conv_w, conv_b, dt_bias, A, D, norm_w, eps, scan_index, scan_index_inv, d_inner, d_state,
+                                  torch.is_grad_enabled())
+
+
 def indexed_scan(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
     """Selective scan of ndir*B token-gathered sequences with the z gather and the inverse (merge) reindex folded in.
     u, delta: [ndir*B, L, Dm]; Bm, Cm: [ndir*B, L, N] views; z: [B, L, Dm] (token order).  Returns the gated output
