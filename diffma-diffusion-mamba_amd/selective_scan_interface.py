@@ -337,7 +337,8 @@ class _SpiralSSDFn(torch.autograd.Function):
         xBC = hip_ops.gather_conv1d_fwd(xbc_in, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)        # [S, L, Cx]
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         # dt is produced per token and per head: gather its rows per direction, broadcast head -> channels
-        dt_g = torch.stack([dt_tok[:, scan_index[k].long()] for k in range(ndir)])                                 # [ndir, B, L, H]
+        idx64 = scan_index.long()
+        dt_g = torch.stack([dt_tok[:, idx64[k]] for k in range(ndir)])                                            # [ndir, B, L, H]
         delta = dt_g.reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din)
         A = A_h.float().repeat_interleave(P)[:, None].expand(Din, N).contiguous()
         Dskip = D_h.float().repeat_interleave(P)
@@ -375,10 +376,12 @@ class _SpiralSSDFn(torch.autograd.Function):
         hip_ops.token_merge(dzs.view(ndir, Bsz, L, Din), out=dzx[..., :Din])
         hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Cx), out=dzx[..., Din:Din + Cx])
         # d(dt): sum the head's channels, put every direction back in token order (adjoint of the row gather), add the directions
-        ddt = ddelta.view(S * L * H, P).float().sum(-1).view(ndir, Bsz, L, H)
-        ddt_tok = ddt[0][:, scan_index_inv[0].long()]
+        # (a matrix-vector product: the generic inner-dimension reduction kernel takes 150 us for this shape, the GEMV 20)
+        ddt = torch.mv(ddelta.view(S * L * H, P), torch.ones(P, dtype=dt_, device=zxbcdt.device)).view(ndir, Bsz, L, H)
+        inv64 = scan_index_inv.long()
+        ddt_tok = ddt[0][:, inv64[0]].float()
         for k in range(1, ndir):
-            ddt_tok = ddt_tok + ddt[k][:, scan_index_inv[k].long()]
+            ddt_tok = ddt_tok + ddt[k][:, inv64[k]].float()
         dzx[..., Din + Cx:].copy_(ddt_tok)
         dA_h = dA.view(H, P * N).sum(-1)
         dD_h = dD.view(H, P).sum(-1)
