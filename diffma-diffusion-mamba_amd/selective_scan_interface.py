@@ -410,17 +410,6 @@ def indexed_scan(u, delta, A, Bm, Cm, D, z, dt_bias, scan_index, Bsz):
                                     torch.is_grad_enabled())
 
 
-class _MergeFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, slabs):
-        ctx.k = slabs.shape[0]
-        return hip_ops.token_merge(slabs.contiguous())
-
-    @staticmethod
-    def backward(ctx, dy):
-        return dy.unsqueeze(0).expand(ctx.k, *dy.shape)
-
-
 class _RmsMergeFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, slabs, weight, eps):
@@ -444,11 +433,6 @@ def rmsnorm_merge(slabs, weight, eps):
     (norm_before_gate = False, block/mamba2.py:349) fused with the 3-way CrossMerge."""
     with torch.autocast(device_type="cuda", enabled=False):
         return _RmsMergeFn.apply(slabs, weight, eps)
-
-
-def merge_slabs(slabs):
-    """[K, B, L, Dm] -> sum over K (CrossMerge after the rows are already in token order)."""
-    return _MergeFn.apply(slabs)
 
 
 def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, chunk_size, initial_states=None,
