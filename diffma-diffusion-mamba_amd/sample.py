@@ -50,13 +50,20 @@ def main(args):
     diffusion = create_diffusion(f"ddim{steps}" if ddim else str(steps))
     n = int(args.sample_global_batch_size // world) or 1
     tokens = model.x_embedder.num_patches
+    from .train import build_ct_encoder
+    ct_encoder = build_ct_encoder(args, latent, device)
     os.makedirs(args.save_dir, exist_ok=True)
     g = torch.Generator(device=device).manual_seed(args.seed * world + rank)
     mk = lambda *s: torch.randn(*s, generator=g, device=device)
     out = []
     for b in range(int(args.get("num_batches", 1))):
         z = mk(n, 4, latent, latent)
-        kw = dict(y=mk(n, 512), y2=mk(n, tokens, 512), w=torch.sigmoid(mk(n, tokens, 1)))
+        if ct_encoder is not None:                     # soft mask + token conditioning from the CT latent (reference sample.py:104)
+            with torch.no_grad():
+                ct_w, ct_y2 = ct_encoder(mk(n, 4, latent, latent))
+            kw = dict(y=mk(n, 512), y2=ct_y2, w=ct_w)
+        else:
+            kw = dict(y=mk(n, 512), y2=mk(n, tokens, 512), w=torch.sigmoid(mk(n, tokens, 1)))
         loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
         denoiser = model.forward
         if device.type == "cuda" and not args.get("no_graph", False):

@@ -61,17 +61,40 @@ def create_logger(logging_dir, rank):
 
 
 class SyntheticLatents:
-    """Stand-in for NpyDataset + frozen encoders: yields (z_mri, y, y2, w) already in latent space."""
+    """Stand-in for NpyDataset + frozen encoders: yields (z_mri, y, y2, w) already in latent space.  With a CT_Encoder the
+    soft mask and the token conditioning come from it, applied to a synthetic CT latent (reference train.py:239-240);
+    otherwise they are drawn directly."""
 
-    def __init__(self, n, latent, tokens, seed):
-        self.n, self.latent, self.tokens, self.seed = n, latent, tokens, seed
+    def __init__(self, n, latent, tokens, seed, ct_encoder=None):
+        self.n, self.latent, self.tokens, self.seed, self.ct_encoder = n, latent, tokens, seed, ct_encoder
 
     def batches(self, batch, device, epoch, rank, world):
         g = torch.Generator(device=device).manual_seed(self.seed * 1000003 + epoch * 1009 + rank)
         per_rank = self.n // world
         for _ in range(per_rank // batch):
             mk = lambda *s: torch.randn(*s, generator=g, device=device)
-            yield mk(batch, 4, self.latent, self.latent), mk(batch, 512), mk(batch, self.tokens, 512), torch.sigmoid(mk(batch, self.tokens, 1))
+            z, y = mk(batch, 4, self.latent, self.latent), mk(batch, 512)
+            if self.ct_encoder is not None:
+                with torch.no_grad():
+                    w, y2 = self.ct_encoder(mk(batch, 4, self.latent, self.latent))
+            else:
+                y2, w = mk(batch, self.tokens, 512), torch.sigmoid(mk(batch, self.tokens, 1))
+            yield z, y, y2, w
+
+
+def build_ct_encoder(args, latent, device):
+    """The frozen CT_Encoder of train.py:158-169 when its checkpoint is there (or `synthetic_ct_encoder: true` asks for a
+    randomly initialised one); None otherwise."""
+    from .ct_encoder import CT_Encoder
+    path = args.get("ct_ckpt", None)
+    have = bool(path) and os.path.isfile(path)
+    if not have and not args.get("synthetic_ct_encoder", False):
+        return None
+    ct = CT_Encoder(img_size=latent, patch_size=int(args.model[-1]), in_channels=4, embed_dim=512, contain_mask_token=True).to(device)
+    if have:
+        from .sample import find_model
+        ct.load_state_dict(find_model(path))
+    return ct.eval().requires_grad_(False)
 
 
 def main(args):
@@ -128,7 +151,8 @@ def main(args):
         raise RuntimeError("real-data training needs the SD-VAE / BiomedCLIP / CT_Encoder weights, which are not available "
                            "offline; run with --synthetic (BASELINE.md section 4)")
     tokens = model.x_embedder.num_patches
-    data = SyntheticLatents(int(args.get("synthetic_samples", 1024)), latent, tokens, args.global_seed)
+    data = SyntheticLatents(int(args.get("synthetic_samples", 1024)), latent, tokens, args.global_seed,
+                            ct_encoder=build_ct_encoder(args, latent, device))
     local_batch = args.global_batch_size // world
     logger.info(f"Dataset contains {data.n}.")
 

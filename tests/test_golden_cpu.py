@@ -255,3 +255,19 @@ def test_product_mamba2_model_has_reference_state_dict_layout():
     net.load_state_dict(sd)
     m = net.blocks[0].mamba1
     assert (m.nheads, m.headdim, m.in_proj.weight.shape[0], m.conv1d.weight.shape[0]) == (2, 64, 2 * 128 + 32 + 2, 160)
+
+
+@pytest.mark.parametrize("tag,img,patch,emb", [("p2", 28, 2, 512), ("p4", 28, 4, 512), ("p7", 28, 7, 64)])
+def test_ct_encoder_matches_reference(tag, img, patch, emb):
+    """G8: soft mask w and token conditioning y2 of the reference CT_Encoder (block/CT_encoder.py) for its own state dict."""
+    from diffma_amd.ct_encoder import CT_Encoder
+
+    g = np.load(os.path.join(G, "g8_ct_encoder.npz"))
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+    ct = CT_Encoder(img_size=img, patch_size=patch, in_channels=4, embed_dim=emb, contain_mask_token=True).eval()
+    assert set(ct.state_dict()) == set(sd) and len(sd) == 9
+    ct.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        w, y2 = ct(torch.from_numpy(g[tag + ".x"]))
+    torch.testing.assert_close(w, torch.from_numpy(g[tag + ".w"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(y2, torch.from_numpy(g[tag + ".y2"]), rtol=1e-5, atol=2e-5)

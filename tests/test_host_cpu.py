@@ -95,3 +95,17 @@ def test_ddp_training_two_ranks_gloo(tmp_path):
     # after 2 optimiser steps the EMA lags the model but is no longer the init
     some = "blocks.0.mamba1.in_proj.weight"
     assert not torch.equal(sd["model"][some], sd["ema"][some])
+
+
+def test_synthetic_batches_through_ct_encoder():
+    """`synthetic_ct_encoder: true`: the soft mask and token conditioning of the synthetic stream come from a CT_Encoder
+    (reference train.py:239-240) instead of being drawn directly."""
+    from diffma_amd.config import load_config  # noqa: F401  (package import check)
+    from diffma_amd.ct_encoder import CT_Encoder
+    from diffma_amd.train import SyntheticLatents
+
+    ct = CT_Encoder(img_size=28, patch_size=7, in_channels=4, embed_dim=512).eval()
+    data = SyntheticLatents(8, 28, 16, seed=0, ct_encoder=ct)
+    z, y, y2, w = next(iter(data.batches(4, torch.device("cpu"), 0, 0, 1)))
+    assert z.shape == (4, 4, 28, 28) and y.shape == (4, 512) and y2.shape == (4, 16, 512) and w.shape == (4, 16, 1)
+    assert float(w.min()) > 0.0 and float(w.max()) < 1.0 and not y2.requires_grad

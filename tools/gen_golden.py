@@ -218,6 +218,21 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g7_tiny_diffma_mamba2.npz"), **g7)
     print("G7 params", sum(p.numel() for p in net2.parameters()), "out abs mean", float(out.abs().mean()))
 
+    # ---- G8 CT_Encoder (soft mask w + token conditioning y2): the reference module itself, seeded random weights ----------
+    from block.CT_encoder import CT_Encoder as RefCT
+    g8 = {}
+    for tag, (img, patch, emb) in {"p2": (28, 2, 512), "p4": (28, 4, 512), "p7": (28, 7, 64)}.items():
+        torch.manual_seed(17)
+        ct = RefCT(img_size=img, patch_size=patch, in_channels=4, embed_dim=emb, contain_mask_token=True).eval()
+        with torch.no_grad():
+            ct.vision_embedding.mask_token.normal_(std=0.02)
+            xin = torch.randn(3, 4, img, img)
+            wgt, y2o = ct(xin)
+        g8.update({f"{tag}.sd.{k}": v.numpy() for k, v in ct.state_dict().items()})
+        g8.update({f"{tag}.x": xin.numpy(), f"{tag}.w": wgt.numpy(), f"{tag}.y2": y2o.numpy()})
+    np.savez_compressed(os.path.join(OUT, "g8_ct_encoder.npz"), **g8)
+    print("G8 CT_Encoder", {k: v.shape for k, v in g8.items() if k.endswith(".w") or k.endswith(".y2")})
+
     # ---- G6 operator vectors from the ORACLE (regression guard for the restatement itself) ---------------------------
     from oracle import mamba_ref
     gen = torch.Generator().manual_seed(5)
