@@ -109,3 +109,42 @@ def test_synthetic_batches_through_ct_encoder():
     z, y, y2, w = next(iter(data.batches(4, torch.device("cpu"), 0, 0, 1)))
     assert z.shape == (4, 4, 28, 28) and y.shape == (4, 512) and y2.shape == (4, 16, 512) and w.shape == (4, 16, 1)
     assert float(w.min()) > 0.0 and float(w.max()) < 1.0 and not y2.requires_grad
+
+
+def _resume_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import diffma_amd.mamba as mamba_mod
+    from diffma_amd import sample as sample_mod
+    from diffma_amd import train as train_mod
+    from diffma_amd.config import Config
+    from diffma_amd.model import DiffMa_models
+
+    mamba_mod.spiral_ssm = _oracle_spiral_ssm                     # test-only substitution (see module docstring)
+    torch.set_num_threads(2)
+    base = dict(model="DiffMa-S/7", image_size=224, dt_rank=16, d_state=16, global_batch_size=2, global_seed=0, lr=1e-4, lr_=1e-4,
+                epochs=1, accumulation_steps=1, log_every=1, ckpt_every=1, results_dir=os.path.join(tmpdir, "res"),
+                autocast=False, synthetic=True, synthetic_samples=16)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    assert train_mod.main(Config(init_from_pretrain_ckpt=False, pretrain_ckpt_path="", init_train_steps=0, max_steps=1, **base)) == 1
+    ck = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmpdir) for f in fs if f.endswith(".pt"))
+    assert len(ck) == 1
+    # resume: weights + EMA come from the checkpoint, the step counter from init_train_steps (reference train.py:137-147)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    assert train_mod.main(Config(init_from_pretrain_ckpt=True, pretrain_ckpt_path=ck[0], init_train_steps=1, max_steps=2, **base)) == 2
+    ck2 = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmpdir) for f in fs if f.endswith("0000002.pt"))
+    assert len(ck2) == 1
+    # what sample.py loads is the EMA of that file, strict
+    net = DiffMa_models["DiffMa-S/7"](input_size=28, dt_rank=16, d_state=16)
+    net.load_state_dict(sample_mod.find_model(ck2[0]), strict=True)
+    first, second = torch.load(ck[0], weights_only=False), torch.load(ck2[0], weights_only=False)
+    # (zero-initialised gates keep the mixers' gradients at zero for the first steps: compare a tensor that does move)
+    assert not torch.equal(first["model"]["final_layer.linear.weight"], second["model"]["final_layer.linear.weight"])
+
+
+def test_checkpoint_resume_and_sampler_load(tmp_path):
+    """Checkpoint dict {"model","ema","opt","args"} (reference train.py:291-303): written, resumed from, and its EMA
+    loaded the way sample.py does."""
+    mp.spawn(_resume_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
