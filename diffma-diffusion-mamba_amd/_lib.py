@@ -22,6 +22,7 @@ DM_F32, DM_BF16, DM_F16 = 0, 1, 2
 DM_FLAG_DELTA_SOFTPLUS = 1
 DM_FLAG_SILU = 2
 DM_FLAG_DOUT_PER_SEQ = 4
+DM_FLAG_A_SHARED = 8
 
 _SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 

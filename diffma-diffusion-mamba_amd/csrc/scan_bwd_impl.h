@@ -129,7 +129,7 @@ __device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
     }
 }
 
-template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS>
+template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS, bool ASH = false>
 __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 3 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
@@ -315,12 +315,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             lds_ld_vec<NS>(Bv, brow);
             const float dlo = opaque(dl[j]);
             const float du = dlo * uu[j];
+            float a_sh = 0.f;
+            if (ASH) a_sh = fast_exp2(A2[0].x * dlo);             // DM_FLAG_A_SHARED: one decay factor for all states of the channel
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                const f32x2 t = A2[k] * dlo;
                 f32x2 a;
-                a.x = fast_exp2(t.x);
-                a.y = fast_exp2(t.y);
+                if (ASH) {
+                    a = (f32x2){a_sh, a_sh};
+                } else {
+                    const f32x2 t = A2[k] * dlo;
+                    a.x = fast_exp2(t.x);
+                    a.y = fast_exp2(t.y);
+                }
                 f32x2 bb;
                 bb.x = Bv[2 * k];
                 bb.y = Bv[2 * k + 1];
@@ -369,6 +375,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 }
                 const float dlo = opaque(dl[j]);
                 const float du = dlo * uu[j];
+                float a_rev = 0.f;
+                if (ASH) a_rev = fast_exp2(A2[0].x * dlo);
                 f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
                 float red[M];
                 u32x4_t pk_dB, pk_dC;
@@ -377,10 +385,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     f32x2 bb, cc;
                     bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
                     cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
-                    const f32x2 t = A2[k] * dlo;
                     f32x2 a;
-                    a.x = fast_exp2(t.x);
-                    a.y = fast_exp2(t.y);
+                    if (ASH) {
+                        a = (f32x2){a_rev, a_rev};
+                    } else {
+                        const f32x2 t = A2[k] * dlo;
+                        a.x = fast_exp2(t.x);
+                        a.y = fast_exp2(t.y);
+                    }
                     const f32x2 hj = h[k];
                     const f32x2 hp = hs[i][k];
                     yp2 += cc * hj;
@@ -462,6 +474,12 @@ template <int N> struct bwd_split { static constexpr int value = (N >= 16) ? 2 :
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {
+    if constexpr (N == 16 && HAS_Z && IDX) {          // the one-exp variant is built for the Mamba-2 call pattern only
+        if ((a.flags & DM_FLAG_A_SHARED) && (a.flags & DM_FLAG_DELTA_SOFTPLUS)) {
+            hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, true, true, true, true>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
+            return;
+        }
+    }
     if (a.flags & DM_FLAG_DELTA_SOFTPLUS)
         hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, HAS_Z, IDX, true>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
     else

@@ -17,7 +17,7 @@
 
 namespace dm {
 
-template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC>
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC, bool ASH = false>
 __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan_fwd_args p) {
     constexpr int NP = N / 2;
     constexpr int ES = (int)sizeof(T);
@@ -87,12 +87,18 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
     for (int j = 0; j < LC; ++j) {
         const float du = dl[j] * uu[j];
         sd += dl[j];
+        float a_sh = 0.0f;
+        if (ASH) a_sh = fast_exp2(A2[0].x * dl[j]);
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const f32x2 t = A2[k] * dl[j];
             f32x2 a, bb;
-            a.x = fast_exp2(t.x);
-            a.y = fast_exp2(t.y);
+            if (ASH) {
+                a = (f32x2){a_sh, a_sh};
+            } else {
+                const f32x2 t = A2[k] * dl[j];
+                a.x = fast_exp2(t.x);
+                a.y = fast_exp2(t.y);
+            }
             bb.x = bc_lds[c][j][2 * k];
             bb.y = bc_lds[c][j][2 * k + 1];
             h[k] = a * h[k] + bb * du;
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
                 Bc[k] = bc_lds[c][j][k];
                 Cc[k] = bc_lds[c][j][N + k];
             }
-            const float y = scan_step<N, HAS_Z, false>(h, A2, Bc, Cc, uu[j], dl[j], zz[j], Dv, 0.0f);
+            const float y = scan_step<N, HAS_Z, false, ASH>(h, A2, Bc, Cc, uu[j], dl[j], zz[j], Dv, 0.0f);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
         }
     }
@@ -156,6 +162,12 @@ static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
 template <typename T, typename TBC, bool HAS_Z, bool IDX>
 static void launch_fwd_chunked2(const dm_scan_fwd_args& a, hipStream_t st) {
     dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq), block(WAVE * CHUNKED_NW);
+    if constexpr (HAS_Z && IDX) {
+        if ((a.flags & DM_FLAG_A_SHARED) && (a.flags & DM_FLAG_DELTA_SOFTPLUS)) {
+            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
     if (a.flags & DM_FLAG_DELTA_SOFTPLUS)
         hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, true, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
     else

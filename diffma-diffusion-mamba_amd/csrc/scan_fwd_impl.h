@@ -26,19 +26,26 @@ namespace dm {
 constexpr int FWD_CKE = 4;     // steps between checkpoints (the backward's sub-chunk length)
 
 // One time step of the recurrence for one lane.
-template <int N, bool HAS_Z, bool SOFTPLUS>
+// ASH (DM_FLAG_A_SHARED): every state of the channel decays with the same factor -> one exp per step.
+template <int N, bool HAS_Z, bool SOFTPLUS, bool ASH = false>
 __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[N / 2], const float (&Bv)[N],
                                            const float (&Cv)[N], float uu, float draw, float zz, float Dv, float bias) {
     float dl = draw + bias;
     if (SOFTPLUS) dl = softplus_f(dl);
     const float du = dl * uu;
     f32x2 acc = (f32x2){0.0f, 0.0f};
+    float a_sh = 0.0f;
+    if (ASH) a_sh = fast_exp2(A2[0].x * dl);
 #pragma unroll
     for (int k = 0; k < N / 2; ++k) {
-        const f32x2 t = A2[k] * dl;
         f32x2 a;
-        a.x = fast_exp2(t.x);
-        a.y = fast_exp2(t.y);
+        if (ASH) {
+            a = (f32x2){a_sh, a_sh};
+        } else {
+            const f32x2 t = A2[k] * dl;
+            a.x = fast_exp2(t.x);
+            a.y = fast_exp2(t.y);
+        }
         f32x2 bb, cc;
         bb.x = Bv[2 * k];
         bb.y = Bv[2 * k + 1];
@@ -54,7 +61,7 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 
 // IDX : z_row_index / out_row_index tables are used (both non-null)
 // CKPT: the state is written to p.ckpt after every FWD_CKE = 4 steps (fp32, or bf16 pairs for bf16 I/O)
-template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF>
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF, bool ASH = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : 1))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
     static_assert(N % 2 == 0, "d_state must be even");
     static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
                 Bc[k] = bc_lds[buf][j][k];
                 Cc[k] = bc_lds[buf][j][N + k];
             }
-            const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
+            const float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
             if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l0 + j + 1);      // l0 is a multiple of PF
         }
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
                 Bc[k] = bc_lds[buf][j][k];
                 Cc[k] = bc_lds[buf][j][N + k];
             }
-            const float y = scan_step<N, HAS_Z, SOFTPLUS>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
+            const float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
             if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l + 1);
         }
@@ -240,6 +247,13 @@ static_assert(SCAN_PF % FWD_CKE == 0, "checkpoints fall on fixed positions of a 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_fwd3(const dm_scan_fwd_args& a, hipStream_t st, dim3 grid) {
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
+    if constexpr (N == 16 && HAS_Z && IDX) {          // the one-exp variant is built for the Mamba-2 call pattern only
+        if ((a.flags & DM_FLAG_A_SHARED) && sp) {
+            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, true, true, SCAN_PF, true>), grid, dim3(WAVE), 0, st, a);
+            else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, false, true, SCAN_PF, true>), grid, dim3(WAVE), 0, st, a);
+            return;
+        }
+    }
     if (a.ckpt) {
         if (sp) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, true, true, SCAN_PF>), grid, dim3(WAVE), 0, st, a);
         else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, HAS_Z, IDX, true, false, SCAN_PF>), grid, dim3(WAVE), 0, st, a);

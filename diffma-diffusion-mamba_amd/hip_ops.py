@@ -9,7 +9,7 @@ from __future__ import annotations
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args,
                    dm_conv_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -110,7 +110,7 @@ def _ckpt_dtype_code(ckpt):
 
 def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
-             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1):
+             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False):
     """u, delta: [S, L, Dm] token-major (last stride 1).  Bm, Cm: [S, L, G*N] views (state stride 1).
     z: [S or S/ndir, Lz, Dm] or None.  A: [Dm, N] fp32.  Returns out [S, L, Dm] (allocated if None)."""
     _require_gpu(u, delta, A, Bm, Cm, z)
@@ -127,7 +127,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.batch_per_dir = batch_per_dir
     a.io_dtype = dtype_code(u)
     a.bc_dtype = dtype_code(Bm)
-    a.flags = DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0
+    a.flags = (DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_A_SHARED if a_shared else 0)
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
@@ -152,7 +152,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
 
 def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
-             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None):
+             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False):
     """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
     already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
     z_row_index is given)."""
@@ -180,7 +180,8 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.batch_per_dir = batch_per_dir
     a.io_dtype = dtype_code(u)
     a.bc_dtype = dtype_code(Bm)
-    a.flags = (DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_DOUT_PER_SEQ if dout_per_seq else 0)
+    a.flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_DOUT_PER_SEQ if dout_per_seq else 0)
+               | (DM_FLAG_A_SHARED if a_shared else 0))
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.dout = _ptr(u), _ptr(delta), _ptr(z), _ptr(dout)

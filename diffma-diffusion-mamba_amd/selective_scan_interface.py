@@ -346,7 +346,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         need_grad = grad_on and any(ctx.needs_input_grad[:7])
         ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, zxbcdt.dtype, zxbcdt.device) if need_grad else None
         ydir = hip_ops.scan_fwd(x, delta, A, Bm, Cm, Dskip, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
-                                batch_per_dir=Bsz, ckpt=ckpt)                                                     # token order, gated
+                                batch_per_dir=Bsz, ckpt=ckpt, a_shared=True)     # token order, gated; one decay per head
         out, rstd = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
         ctx.save_for_backward(zxbcdt, conv_w, conv_b, xBC, delta, A, Dskip, dt_bias, ckpt, ydir, rstd, norm_w, scan_index, scan_index_inv)
         ctx.meta = (Din, N, H, P, eps, dt_bias_h.dtype, A_h.dtype, D_h.dtype)
@@ -367,7 +367,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         _, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(
             x, delta, A, Bm, Cm, Dskip, zxbcdt[..., :Din], dt_bias, dyd.view(S, L, Din), ckpt, True, z_row_index=scan_index,
-            out_row_index=scan_index, batch_per_dir=Bsz, dout_per_seq=True, du_out=dxBC[..., :Din])
+            out_row_index=scan_index, batch_per_dir=Bsz, dout_per_seq=True, du_out=dxBC[..., :Din], a_shared=True)
         dxBC[..., Din:Din + N].copy_(dB)
         dxBC[..., Din + N:].copy_(dC)
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(zxbcdt[..., Din:Din + Cx], conv_w, conv_b, dxBC, row_index=scan_index,

@@ -46,6 +46,9 @@ typedef enum { DM_F32 = 0, DM_BF16 = 1, DM_F16 = 2 } dm_dtype;
 enum {
     DM_FLAG_DELTA_SOFTPLUS = 1, /* delta = softplus(delta + bias)                     */
     DM_FLAG_SILU = 2,           /* conv: apply SiLU after the bias add                */
+    DM_FLAG_A_SHARED = 8,       /* scan: A[d][n] is the same for every state n of a channel (Mamba-2 / SSD: one decay per
+                                   head), so the kernels evaluate ONE exp per (channel, step) instead of dstate.  A is still
+                                   passed as [dim][dstate]; the caller vouches for the property.                         */
     DM_FLAG_DOUT_PER_SEQ = 4    /* scan bwd with row indices: dout is [nseq][row][d] (one gradient per direction,
                                    Mamba-2: the gated RMSNorm sits between the scan and the merge) instead of
                                    [batch_per_dir][row][d] shared by the directions  */
