@@ -236,6 +236,27 @@ def test_mamba2_mixer_forward_backward(gpu):
         assert rel_l2(p.grad.cpu(), params[k].grad) <= 5e-4, k
 
 
+def test_mamba2_mixer_inference_chunk_parallel_scan(gpu):
+    """Under no_grad at L = 196 the small launch takes the chunk-parallel scan in its one-decay-per-head form
+    (scan_fwd_chunked.h with DM_FLAG_A_SHARED); same oracle as above."""
+    from diffma_amd.mamba2 import Mamba2
+    from diffma_amd.tools import spiral
+    from oracle.mamba2_ref import mamba2_spiral_forward_ref
+
+    torch.manual_seed(2)
+    n = 14
+    orders, inverses = spiral(n)
+    lists = (orders[2], orders[3], inverses[2], inverses[3])
+    mix = Mamba2(d_model=64, d_state=16, d_conv=4, expand=2, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+                 origina_list_reversal=lists[3]).to(gpu).eval()
+    x = torch.randn(2, n * n, 64, device=gpu)
+    with torch.no_grad():
+        y = mix(x, "spiral")
+        params = {k: v.detach().cpu().double() for k, v in mix.state_dict().items()}
+        yr = mamba2_spiral_forward_ref(x.cpu().double(), params, lists, headdim=64, dtype=torch.float64)
+    assert rel_l2(y.cpu(), yr) <= 1e-4, rel_l2(y.cpu(), yr)
+
+
 def test_mamba_split_conv1d_scan_combined_signature(gpu):
     """The reference's keyword call (block/mamba2.py:392-410) against the oracle restatement, incl. a strided input."""
     from diffma_amd.selective_scan_interface import mamba_split_conv1d_scan_combined
