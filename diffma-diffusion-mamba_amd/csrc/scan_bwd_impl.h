@@ -4,23 +4,24 @@
 // Replaces selective_scan_cuda.bwd (autograd of mamba_inner_fn / selective_scan_fn on the training
 // path, reference train.py:259).  Equations: SURVEY.md A.1-bwd.
 //
-// Layout: token-major like the forward, but a lane owns a (channel, state-slice) pair: with SPLIT = 2 the
-// 64 lanes of a wave are 32 channels x 2 slices of d_state/2 states.  The backward needs, per lane, the
-// recomputed in-chunk states (hs[j] = state before step j), the adjoint carry, the dA accumulator and the
-// chunk's inputs; a whole channel per lane (16 states) is ~270 live VGPRs and spills.  The price is a DPP sum
-// of y, G.B and the dA-term over the slices per time step and a replicated softplus/silu per slice.
+// Layout: token-major like the forward.  A lane owns SPLIT-th of a channel's states: for d_state 16 a whole channel
+// (SPLIT = 1, 64 channels per wave, 232 VGPRs, 2 waves/SIMD), for d_state 32 half of one (SPLIT = 2).  With the
+// forward's checkpoints every 4 steps only 4 recomputed states per lane are live (64 VGPRs for 16 states); the earlier
+// 8-step scheme needed ~270 VGPRs for a whole channel and therefore ran 2 lanes per channel, which replicated every
+// per-channel instruction (softplus, silu', conversions, stores: a third of the issue slots) -- a whole channel per
+// lane measures 11 % faster despite the lower occupancy.
 //
 // Per staging chunk of CK = 8 steps:
 //   1. per SUB = 4 step sub-chunk: reload the state slice from the forward's checkpoint (every 4 steps; bf16 pairs
 //      for bf16 I/O, i.e. the same bytes as fp32 every 8) and recompute the 4 in-chunk states into registers
-//      (163 VGPRs => 3 waves/SIMD; holding 8 states needs 196 => 2 waves/SIMD and measures slower),
+//      instead of re-advancing from an earlier state,
 //   2. walk the sub-chunk backwards carrying  carry_n = a_{j+1,n} * dL/dh_{j+1,n},
 //      accumulating dA / dD / dbias per lane (written once as per-sequence partials, no atomics),
 //   3. dB/dC: the per-lane products are reduce-scattered over the wave's 4 lane groups (16-bit I/O: two
 //      v_mfma_f32_16x16x32_bf16 with 0/1 selector fragments on the otherwise idle matrix pipe; fp32 I/O: permlane
 //      swaps), written to LDS per row position, and after the chunk (one barrier) summed over the row positions
-//      of a slice and the 4 waves and stored as one row of partials per (step, 128-channel workgroup); the
-//      dim/128 workgroups of a sequence are summed by the caller (deterministic).
+//      of a slice and the 4 waves and stored as one row of partials per (step, workgroup = 256 channels at d_state 16);
+//      the workgroups of a sequence are summed by the caller (deterministic).
 // One sweep over u, delta, z, dout (read) and du, ddelta, dz (write): 28 B/element in fp32 + checkpoints.
 #include <type_traits>
 #include "dm_common.h"
@@ -130,10 +131,10 @@ __device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
 }
 
 template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS, bool ASH = false>
-__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 3 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 2 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
-    constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M == 16;   // dB/dC lane-group sums on the matrix pipe
+    constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M % 16 == 0;   // dB/dC lane-group sums on the matrix pipe
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
@@ -228,8 +229,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const int n = (cc < N) ? cc : cc - N;
                 const int qq = n / NS;
                 const int vidx = (cc < N) ? n % NS : NS + n % NS;                 // value index in [0, M) inside slice qq
-                const int lane0 = (MFMA_RED ? 16 * (vidx >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
-                const int reg = MFMA_RED ? (vidx & 3) : (vidx >> 2);
+                const int lane0 = (MFMA_RED ? 16 * ((vidx & 15) >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
+                const int reg = MFMA_RED ? 4 * (vidx >> 4) + (vidx & 3) : (vidx >> 2);
                 float acc = 0.f;
 #pragma unroll
                 for (int w = 0; w < BWD_WAVES; ++w)
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (ASH) a_rev = fast_exp2(A2[0].x * dlo);
                 f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
                 float red[M];
-                u32x4_t pk_dB, pk_dC;
+                uint32_t pk_all[M / 2];                        // bf16 pairs: [dB pairs (NPL) | dC pairs (NPL)]
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) {
                     f32x2 bb, cc;
@@ -407,8 +408,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
                     if constexpr (MFMA_RED) {
-                        pk_dB[k] = pack_bf16(dBp.x, dBp.y);
-                        pk_dC[k] = pack_bf16(dCp.x, dCp.y);
+                        pk_all[k] = pack_bf16(dBp.x, dBp.y);
+                        pk_all[NPL + k] = pack_bf16(dCp.x, dCp.y);
                     } else {
                         red[2 * k] = dBp.x;
                         red[2 * k + 1] = dBp.y;
@@ -436,8 +437,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
                 if constexpr (MFMA_RED) {
-                    const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, pk_dB, pk_dC);
-                    *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot]) = dsum;
+#pragma unroll
+                    for (int g16 = 0; g16 < M / 16; ++g16) {   // 16 values (8 pairs) per pair of MFMAs; register r of group g16 = value 16*g16 + 4*(lane>>4) + r
+                        const u32x4_t lo = {pk_all[8 * g16], pk_all[8 * g16 + 1], pk_all[8 * g16 + 2], pk_all[8 * g16 + 3]};
+                        const u32x4_t hi = {pk_all[8 * g16 + 4], pk_all[8 * g16 + 5], pk_all[8 * g16 + 6], pk_all[8 * g16 + 7]};
+                        const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
+                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot + 4 * g16]) = dsum;
+                    }
                 } else {
                     lane_group_reduce<M>(red);
 #pragma unroll
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <int N> struct bwd_split { static constexpr int value = (N >= 16) ? 2 : 1; };   // lanes per channel
+template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : 1; };   // lanes per channel
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {
