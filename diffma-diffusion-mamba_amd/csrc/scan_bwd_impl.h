@@ -139,7 +139,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
     // that the strided reads of the chunk-end summation spread over all LDS banks
-    constexpr int RED_ROW = WAVE * R + 4 * 2 * R;
+    // (registers go to LDS in groups of 4: [group][lane][4] keeps every ds_write_b128 and the strided flush reads conflict-free)
+    static_assert(R % 4 == 0, "lane-group totals are stored 4 registers at a time");
+    constexpr int RED_HALF = WAVE * 4 + 4 * 8;
+    constexpr int RED_ROW = (R / 4) * RED_HALF;
     __shared__ __attribute__((aligned(16))) float red_lds[BWD_WAVES][CK][RED_ROW];
     __shared__ __attribute__((aligned(16))) float bc_lds[2][CK][2 * N];   // [B row | C row] of every step of a chunk, all waves share a sequence
 
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 
     u32x4_t sel_lo, sel_hi;
     if (MFMA_RED) mfma_selectors(lane, sel_lo, sel_hi);
-    const int red_slot = lane * R + (lane >> 4) * 2 * R;
+    const int red_slot = lane * 4 + (lane >> 4) * 8;                 // + RED_HALF per group of 4 registers
 
     // B/C rows of a chunk: CK*2N values, fetched cooperatively (one or two per thread), one chunk ahead
     constexpr int BC_PER_THREAD = (CK * 2 * N + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
                 for (int w = 0; w < BWD_WAVES; ++w)
 #pragma unroll
-                    for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(lane0 + SPLIT * t) * R + (lane0 >> 4) * 2 * R + reg];
+                    for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(reg >> 2) * RED_HALF + (lane0 + SPLIT * t) * 4 + (lane0 >> 4) * 8 + (reg & 3)];
                 p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
             }
         }
@@ -442,17 +445,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                         const u32x4_t lo = {pk_all[8 * g16], pk_all[8 * g16 + 1], pk_all[8 * g16 + 2], pk_all[8 * g16 + 3]};
                         const u32x4_t hi = {pk_all[8 * g16 + 4], pk_all[8 * g16 + 5], pk_all[8 * g16 + 6], pk_all[8 * g16 + 7]};
                         const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
-                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot + 4 * g16]) = dsum;
+                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][g16 * RED_HALF + red_slot]) = dsum;
                     }
                 } else {
                     lane_group_reduce<M>(red);
 #pragma unroll
                     for (int r4 = 0; r4 < R / 4; ++r4)
-                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][red_slot + 4 * r4]) = (f32x4){red[4 * r4], red[4 * r4 + 1], red[4 * r4 + 2], red[4 * r4 + 3]};
-                    if constexpr (R % 4 != 0) {
-#pragma unroll
-                        for (int r = R - R % 4; r < R; ++r) red_lds[wave][j][red_slot + r] = red[r];
-                    }
+                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][r4 * RED_HALF + red_slot]) = (f32x4){red[4 * r4], red[4 * r4 + 1], red[4 * r4 + 2], red[4 * r4 + 3]};
                 }
             }
         }
