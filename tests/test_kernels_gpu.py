@@ -170,6 +170,35 @@ def test_scan_linearity_in_u_full_size(gpu):
     torch.testing.assert_close(y12, y1 + y2, rtol=1e-4, atol=2e-5 * scale)
 
 
+def test_scan_bwd_linearity_in_dout_full_size(gpu):
+    """Size-independent property of the adjoint at the bench's channel count: every gradient is linear in dout,
+    and the input gradients agree with the forward through <dout, J du> = <J^T dout, du> (dot-product test in u)."""
+    from diffma_amd import hip_ops
+
+    S, L, Dm, N = 48, 196, 1024, 16
+    g = torch.Generator(device="cpu").manual_seed(1)
+    mk = lambda *s: torch.randn(*s, generator=g).to(gpu)
+    u, delta, z = mk(S, L, Dm), mk(S, L, Dm) * 0.5, mk(S, L, Dm)
+    A = -(torch.rand(Dm, N, generator=g) * 4 + 0.2).to(gpu)
+    Bm, Cm, Dp, bias = mk(S, L, N), mk(S, L, N), mk(Dm), mk(Dm) * 0.5
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, torch.float32, gpu)
+    f = lambda uu: hip_ops.scan_fwd(uu, delta, A, Bm, Cm, Dp, z, bias, True, ckpt=ckpt)
+    f(u)
+    bwd = lambda d: hip_ops.scan_bwd(u, delta, A, Bm, Cm, Dp, z, bias, d, ckpt, True)
+    d1, d2 = mk(S, L, Dm), mk(S, L, Dm)
+    r12, r1, r2 = bwd(d1 + d2), bwd(d1), bwd(d2)
+    for name, a, b, c in zip(("du", "ddelta", "dz", "dB", "dC", "dA", "dD", "dbias"), r12, r1, r2):
+        scale = max(a.abs().max().item(), 1e-6)
+        assert torch.isfinite(a).all(), name
+        torch.testing.assert_close(a, b + c, rtol=2e-4, atol=3e-5 * scale, msg=lambda m, n=name: f"{n}: {m}")
+    # dot-product test: the operator is linear in u, so <d1, f(v) - f(0)> == <J_u^T d1, v> for any v
+    v = mk(S, L, Dm)
+    lhs = (d1.double() * (f(v).double() - f(torch.zeros_like(v)).double())).sum()
+    f(u)                                                        # restore the checkpoints of the point bwd was taken at
+    rhs = (r1[0].double() * v.double()).sum()
+    assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), abs(rhs), 1.0), (float(lhs), float(rhs))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Bsz,L,Dm,W", [(2, 196, 1024, 4), (3, 49, 128, 4), (1, 16, 64, 3), (2, 5, 200, 2), (1, 1, 64, 4)])
 def test_gather_conv_fwd_matches_oracle(gpu, dtype, Bsz, L, Dm, W):
