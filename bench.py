@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="DiffMa-L/2")
-    ap.add_argument("--batch-per-gpu", type=int, default=256)
+    ap.add_argument("--batch-per-gpu", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
     ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")

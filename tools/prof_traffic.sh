@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/traffic
 mkdir -p $OUT
 for dt in bf16 fp32; do
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 768 --only scan_bwd > $OUT/f_$dt.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 768 --only scan_bwd > $OUT/w_$dt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd > $OUT/f_$dt.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd > $OUT/w_$dt.log 2>&1
 done
 python - <<PY
 import sqlite3, glob, json
