@@ -124,8 +124,10 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_fwd_kernel(const dm_ln_m
 
 template <typename TX, typename TY, typename TM, int VEC, int NIT>
 __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_mod_args p) {
-    __shared__ float lds[LN_WAVES][4][64 * LN_MAXE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float lds[LN_WAVES][64 * NIT * VEC];            // one of the 4 partial-sum rows at a time (64 KB for all four
+                                                                // at once capped the occupancy of this HBM-bound kernel at 2 WGs/CU)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // keep the row arithmetic scalar
     const int C = p.C1 + p.C2;
     const int bpb = (p.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
     const int b = blockIdx.x / bpb, blk = blockIdx.x - b * bpb;
@@ -196,27 +198,25 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
             }
         }
     }
-    // ---- one partial row per block: sum the 4 waves through LDS -----------------------------------------
+    // ---- one partial row per block and quantity: sum the 4 waves through LDS -----------------------------
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
+    for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) {
-            const int c = (it * 64 + lane) * VEC + j;
-            if (c < 64 * LN_MAXE) {
-                lds[wave][0][c] = a_sh[it][j];
-                lds[wave][1][c] = a_sc[it][j];
-                lds[wave][2][c] = a_g[it][j];
-                lds[wave][3][c] = a_b[it][j];
+        for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const int c = (it * 64 + lane) * VEC + j;
+                lds[wave][c] = (k == 0) ? a_sh[it][j] : (k == 1) ? a_sc[it][j] : (k == 2) ? a_g[it][j] : a_b[it][j];
             }
         }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 4 * C; e += 64 * LN_WAVES) {
-        const int k = e / C, c = e - k * C;
-        float acc = 0.f;
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 64 * LN_WAVES) {
+            float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < LN_WAVES; ++w) acc += lds[w][k][c];
-        p.part[((int64_t)blockIdx.x * 4 + k) * C + c] = acc;
+            for (int w = 0; w < LN_WAVES; ++w) acc += lds[w][c];
+            p.part[((int64_t)blockIdx.x * 4 + k) * C + c] = acc;
+        }
+        __syncthreads();
     }
 }
 
