@@ -266,9 +266,27 @@ def main():
         }
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":
             res["cpu_baseline"] = cpu_baseline(args, tokens)
-        print(json.dumps(res), flush=True)
+    # RCCL writes its banner / warnings through C stdio (block-buffered on a pipe, NCCL_DEBUG=VERSION is set on the GPU boxes):
+    # every rank flushes that before the group goes away, and rank 0 prints afterwards, so that the JSON line is the LAST line
+    # of the merged stdout
+    import ctypes
+
+    def flush_all():
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
+        sys.stdout.flush()
+
     if world > 1 or force_ddp:
+        flush_all()
+        dist.barrier()
         dist.destroy_process_group()
+    flush_all()
+    if rank == 0:
+        if world > 1:
+            time.sleep(1.0)                                      # let the other ranks' exit-time output drain first
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
