@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import block_ops
 from .mamba import Mamba
+from .selective_scan_interface import linear_splitk
 
 
 def modulate(x, shift, scale):
@@ -59,7 +60,9 @@ class Spiral_MambaBlock(nn.Module):
             x_ssm = self.mamba1(x_ssm, "spiral")
             w_ssm = self.mamba2(w_ssm, "spiral")
             net = self.attention_network
-            a = net[4](net[3](net[2](net[1](block_ops.ln_cat(x_ssm, w_ssm, net[0])))))
+            # the two Linear layers of the fusion MLP through linear_splitk: their weight gradients reduce over B*L rows
+            hcat = block_ops.ln_cat(x_ssm, w_ssm, net[0])
+            a = net[4](linear_splitk(net[2](linear_splitk(hcat, net[1].weight, net[1].bias)), net[3].weight, net[3].bias))
             return block_ops.blend_residual(x, x_ssm, w_ssm, a, gate)
         x_ssm = modulate(self.norm1(x), shift, scale)
         w_ssm = x_ssm * w
