@@ -30,10 +30,12 @@ def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = Fal
     tunable.enable(True)
     tunable.tuning_enable(bool(tune_missing))
     if tune_missing:
-        tunable.set_max_tuning_duration(20)
+        # DIFFMA_TUNE_MS: time budget per candidate solution (default 20 ms; 100+ gives a steadier ranking);
+        # DIFFMA_TUNE_FRESH=1: ignore the recorded table and re-time every shape (tools/tune_gemm.sh --fresh)
+        tunable.set_max_tuning_duration(int(os.environ.get("DIFFMA_TUNE_MS", "20")))
         tunable.set_filename(write_file or os.path.join(os.getcwd(), "diffma_gemm_tuning.csv"), False)
     else:
         tunable.set_filename(path, False)
-    if os.path.exists(path):
+    if os.path.exists(path) and not (tune_missing and os.environ.get("DIFFMA_TUNE_FRESH") == "1"):
         tunable.read_file(path)
     return True
