@@ -149,7 +149,7 @@ def _tn_splitk(a, b):
         if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23):
             pa = a.view(C, M // C, a.shape[1]).transpose(1, 2)
             pb = b.view(C, M // C, b.shape[1])
-            return torch.bmm(pa, pb).float().sum(0)
+            return torch.bmm(pa, pb).sum(0, dtype=torch.float32)      # the cast is fused into the reduction
     return (a.t() @ b).float()
 
 
@@ -177,7 +177,7 @@ class _LinearSplitKFn(torch.autograd.Function):
             x2 = xc.reshape(-1, xc.shape[-1])
             dx = (dy2 @ wc).view(xc.shape).to(x_dt) if ctx.needs_input_grad[0] else None
             dw = _tn_splitk(dy2.contiguous(), x2.contiguous()).to(w_dt) if ctx.needs_input_grad[1] else None
-            db = dy2.float().sum(0).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
+            db = dy2.sum(0, dtype=torch.float32).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
