@@ -83,6 +83,7 @@ dm_merge_args = _make_struct("dm_merge_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
+dm_colsum_args = _make_struct("dm_colsum_args")
 
 _lib = None
 _lock = threading.Lock()
@@ -115,7 +116,7 @@ def load():
             fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
             if args in ("void", ""):
                 fn.argtypes = []
-            elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):
+            elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

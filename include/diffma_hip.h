@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 7
+#define DM_ABI_VERSION 8
 
 typedef enum {
     DM_OK = 0,
@@ -295,6 +295,18 @@ typedef struct {
 int dm_rmsnorm_merge_fwd(const dm_rmsnorm_merge_args *args, void *stream);
 int dm_rmsnorm_merge_bwd(const dm_rmsnorm_merge_args *args, void *stream);
 int dm_rmsnorm_merge_rows_per_block(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Column sums of a tall contiguous fp32 matrix: out[c] = sum_r in[r][c].  Reduces the per-sequence partial rows the
+ * scan backward writes (dA [nseq][dim*dstate], dD / ddelta_bias [nseq][dim]); deterministic.  cols % 4 == 0.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *in;
+    float *out;
+    int64_t rows, cols;
+} dm_colsum_args;
+
+int dm_colsum_f32(const dm_colsum_args *args, void *stream);
 
 /* Library introspection. */
 int dm_abi_version(void);

@@ -373,3 +373,14 @@ def test_rmsnorm_merge_matches_torch(gpu, dtype, C, rows):
     torch.testing.assert_close(out.float().cpu().double(), ref.detach(), rtol=rtol, atol=sc(ref.detach()))
     torch.testing.assert_close(dy.float().cpu().double(), yr.grad, rtol=rtol, atol=sc(yr.grad))
     torch.testing.assert_close(dw.cpu().double(), wr.grad, rtol=max(rtol, 1e-3), atol=sc(wr.grad))
+
+
+@pytest.mark.parametrize("R,C", [(1536, 16384), (37, 1024), (5, 4), (96, 200)])
+def test_colsum_matches_torch(gpu, R, C):
+    """dm_colsum_f32 (reduces the scan backward's per-sequence dA / dD / dbias partial rows) vs an fp64 sum."""
+    from diffma_amd import hip_ops
+
+    x = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C))
+    got = hip_ops.colsum(x.to(gpu)).cpu().double()
+    ref = x.double().sum(0)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, ref.abs().max().item()))
