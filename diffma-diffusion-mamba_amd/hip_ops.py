@@ -152,7 +152,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
 
 def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
-             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False):
+             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False, dbc_out=None):
     """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
     already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
     z_row_index is given)."""
@@ -206,7 +206,11 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
         + (scan_nchunk(L, ckpt_every) - 1) * S * (ckpt.shape[2] if ckpt is not None else N) * Dm * 4
     _launch("dm_selective_scan_bwd", a, u, nbytes)
-    dBCs = dBC.sum(dim=2)                       # [S, L, 2N] fp32, deterministic
+    if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype): reduce straight into the caller's buffer
+        torch.sum(dBC, dim=2, dtype=dbc_out.dtype, out=dbc_out)
+        dBCs = dbc_out
+    else:
+        dBCs = dBC.sum(dim=2)                   # [S, L, 2N] fp32, deterministic
     dB, dC = dBCs[..., :N], dBCs[..., N:]
     return (du, ddelta, dz, dB, dC, colsum(dA.view(S, Dm * N)).view(Dm, N), colsum(dD) if dD is not None else None,
             colsum(dbias) if dbias is not None else None)

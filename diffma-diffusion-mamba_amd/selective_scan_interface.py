@@ -237,15 +237,14 @@ class _SpiralSSMFn(torch.autograd.Function):
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         z_view = xz[..., Din:]
-        du, ddelta, dz, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(
-            xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
-            out_row_index=scan_index, batch_per_dir=Bsz)
         M = ndir * Bsz * L
-        ddelta2 = ddelta.view(M, Din)
         dx_dbl = torch.empty((M, R + 2 * N), dtype=dt_, device=xz.device)
+        du, ddelta, dz, _, _, dA, dD, dbias = hip_ops.scan_bwd(
+            xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
+            out_row_index=scan_index, batch_per_dir=Bsz,
+            dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
+        ddelta2 = ddelta.view(M, Din)
         dx_dbl[:, :R] = ddelta2 @ Wdt.to(dt_)
-        dx_dbl[:, R:R + N].copy_(dB.reshape(M, N))
-        dx_dbl[:, R + N:].copy_(dC.reshape(M, N))
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
@@ -365,11 +364,10 @@ class _SpiralSSDFn(torch.autograd.Function):
         dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
         dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
-        _, ddelta, dzs, dB, dC, dA, dD, dbias = hip_ops.scan_bwd(
+        _, ddelta, dzs, _, _, dA, dD, dbias = hip_ops.scan_bwd(
             x, delta, A, Bm, Cm, Dskip, zxbcdt[..., :Din], dt_bias, dyd.view(S, L, Din), ckpt, True, z_row_index=scan_index,
-            out_row_index=scan_index, batch_per_dir=Bsz, dout_per_seq=True, du_out=dxBC[..., :Din], a_shared=True)
-        dxBC[..., Din:Din + N].copy_(dB)
-        dxBC[..., Din + N:].copy_(dC)
+            out_row_index=scan_index, batch_per_dir=Bsz, dout_per_seq=True, du_out=dxBC[..., :Din], a_shared=True,
+            dbc_out=dxBC[..., Din:])                                             # dB | dC land in their xBC columns
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(zxbcdt[..., Din:Din + Cx], conv_w, conv_b, dxBC, row_index=scan_index,
                                                                ndir=ndir, silu=True)                              # token order
         dzx = torch.empty_like(zxbcdt)
