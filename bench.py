@@ -41,8 +41,10 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
     ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
     ap.add_argument("--global-seed", type=int, default=0)
-    ap.add_argument("--gemm-tuning", default="file", choices=["file", "off", "tune"],
-                    help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): recorded table / library default / time unseen shapes")
+    ap.add_argument("--gemm-tuning", default="file", choices=["file", "frozen", "off", "tune"],
+                    help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): file = recorded table, shapes it does not know "
+                         "are timed once during the warm-up steps; frozen = recorded table only; off = library defaults; "
+                         "tune = like file and the learnt records are written to gpurun_out/ (tools/tune_gemm.sh)")
     ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
@@ -128,8 +130,11 @@ def main():
     _lib.load()                                                  # fail loudly if the HIP library is missing
     if args.gemm_tuning != "off":
         from diffma_amd import gemm_tuning
-        gemm_tuning.enable_tuned_gemms(tune_missing=args.gemm_tuning == "tune",
-                                       write_file=os.path.join(os.getcwd(), "gpurun_out", f"gemm_tuning_rank{rank}.csv"))
+        wf = None
+        if args.gemm_tuning == "tune":
+            os.makedirs(os.path.join(os.getcwd(), "gpurun_out"), exist_ok=True)
+            wf = os.path.join(os.getcwd(), "gpurun_out", f"gemm_tuning_rank{rank}.csv")
+        gemm_tuning.enable_tuned_gemms(tune_missing=args.gemm_tuning != "frozen", write_file=wf)
     torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
     model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=args.use_mamba2)
     rerandomize_zero_init(model, 1)

@@ -19,10 +19,12 @@ import torch
 TUNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned", "gemm_gfx950.csv")
 
 
-def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = False, write_file: str | None = None) -> bool:
-    """Use the recorded GEMM solutions.  tune_missing=True additionally times unseen shapes on first use (adds
-    ~1 s per new shape; worthwhile for long training runs) and, with write_file, saves the merged table.
-    Returns False (and changes nothing) when no GPU is present."""
+def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = True, write_file: str | None = None) -> bool:
+    """Use the recorded GEMM solutions.  tune_missing=True (default) additionally times unseen shapes on first use
+    (~1 s per new shape, once) and saves what it learnt to write_file (default: a file in the temp directory).
+    That is not optional polish: for a shape without a record the libraries' default path queries the hipBLASLt
+    heuristics on EVERY batched-GEMM call (~1-5 ms of host time each) and the training step becomes host-bound
+    (DiffMa-L/2 at batch 256: 264 ms/step instead of 155).  Returns False (and changes nothing) without a GPU."""
     if not torch.cuda.is_available():
         return False
     import torch.cuda.tunable as tunable
@@ -33,7 +35,8 @@ def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = Fal
         # DIFFMA_TUNE_MS: time budget per candidate solution (default 20 ms; 100+ gives a steadier ranking);
         # DIFFMA_TUNE_FRESH=1: ignore the recorded table and re-time every shape (tools/tune_gemm.sh --fresh)
         tunable.set_max_tuning_duration(int(os.environ.get("DIFFMA_TUNE_MS", "20")))
-        tunable.set_filename(write_file or os.path.join(os.getcwd(), "diffma_gemm_tuning.csv"), False)
+        import tempfile
+        tunable.set_filename(write_file or os.path.join(tempfile.gettempdir(), f"diffma_gemm_tuning_{os.getpid()}.csv"), False)
     else:
         tunable.set_filename(path, False)
     if os.path.exists(path) and not (tune_missing and os.environ.get("DIFFMA_TUNE_FRESH") == "1"):

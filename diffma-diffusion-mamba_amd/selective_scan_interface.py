@@ -244,8 +244,8 @@ class _SpiralSSMFn(torch.autograd.Function):
             out_row_index=scan_index, batch_per_dir=Bsz,
             dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
-        torch.mm(ddelta2, Wdt.to(dt_), out=dx_dbl[:, :R])                 # BLAS writes the strided (ld = R+2N) block directly
-        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R]).to(Wdt.dtype)                   # [Din, R]
+        dx_dbl[:, :R] = ddelta2 @ Wdt.to(dt_)      # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
+        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
         dxc = du.view(M, Din).addmm_(dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)

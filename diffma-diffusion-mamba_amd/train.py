@@ -111,7 +111,7 @@ def main(args):
     torch.manual_seed(args.global_seed * world + rank)
     if device.type == "cuda":
         from .gemm_tuning import enable_tuned_gemms
-        enable_tuned_gemms(tune_missing=True)       # long run: timing an unseen GEMM shape once (~1 s) pays for itself
+        enable_tuned_gemms()          # recorded table; unseen GEMM shapes are timed once on first use
 
     experiment_dir = checkpoint_dir = None
     if rank == 0:
