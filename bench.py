@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
-    ap.add_argument("--graph", action="store_true", help="sample mode: replay the denoiser step from a captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (sample mode: the denoiser call; train mode, 1 GPU: the whole optimisation step -- for small batches where the eager step is host-bound)")
     return ap.parse_args()
 
 
@@ -153,18 +153,27 @@ def main():
         if world > 1 or force_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
-        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True)
+        graph_train = args.graph and world == 1 and not force_ddp          # DDP keeps the eager step (bucketed all-reduce)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True, capturable=graph_train)
         net.train()
+        if graph_train:
+            from diffma_amd.graphed import GraphedTrainStep
+            gstep = GraphedTrainStep(model, ema, opt, diffusion, batch["z"], torch.zeros(B, device=dev, dtype=torch.long),
+                                     kw["y"], kw["y2"], kw["w"], autocast_dtype=amp, ema_decay=0.999)
 
-        def step():
-            t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
-            with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
-                loss = diffusion.training_losses(net, batch["z"], t, kw)["loss"].mean()
-            loss.backward()
-            opt.step()
-            update_ema(ema, model)
-            opt.zero_grad(set_to_none=True)
-            return loss
+            def step():
+                t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
+                return gstep.step(batch["z"], t, kw["y"], kw["y2"], kw["w"])
+        else:
+            def step():
+                t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
+                with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                    loss = diffusion.training_losses(net, batch["z"], t, kw)["loss"].mean()
+                loss.backward()
+                opt.step()
+                update_ema(ema, model)
+                opt.zero_grad(set_to_none=True)
+                return loss
     else:
         model.eval()
         sdiff = create_diffusion("250" if args.sampler == "ddpm250" else "ddim50")
@@ -229,6 +238,18 @@ def main():
             hip_ops.set_timer(None)
             ksum = timer.summary()
             kernel_source = "2 eager forwards after the timed region (the timed steps replay a hipGraph)"
+        elif not ksum:                                   # graphed training step: time the kernels of 2 eager steps instead
+            hip_ops.set_timer(timer)
+            for _ in range(2):
+                t_ = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
+                with torch.autocast("cuda", dtype=amp, enabled=amp is not None):
+                    l_ = diffusion.training_losses(net, batch["z"], t_, kw)["loss"].mean()
+                l_.backward()
+                opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            hip_ops.set_timer(None)
+            ksum = timer.summary()
+            kernel_source = "2 eager forward+backward passes after the timed region (the timed steps replay a hipGraph)"
         kernels = {}
         for name, r in ksum.items():
             gbps = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
@@ -259,7 +280,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
             "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
-            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" if args.mode == "train"
+            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1) else "") if args.mode == "train"
                        else f"{args.model} {'p_sample step (250-step respaced DDPM)' if args.sampler == 'ddpm250' else 'ddim_sample step (50-step DDIM)'}, batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},

@@ -65,7 +65,9 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.original_num_steps)
+        if not hasattr(self, "_device_maps"):
+            self._device_maps = {}                      # shared by every wrapper: one host-to-device copy per (device, dtype), ever
+        return _WrappedModel(model, self.timestep_map, self.original_num_steps, self._device_maps)
 
     def _scale_timesteps(self, t):
         return t
@@ -74,9 +76,9 @@ class SpacedDiffusion(GaussianDiffusion):
 class _WrappedModel:
     """Translates respaced step indices to original ones; the lookup table lives on the device."""
 
-    def __init__(self, model, timestep_map, original_num_steps):
+    def __init__(self, model, timestep_map, original_num_steps, device_maps=None):
         self.model, self.timestep_map, self.original_num_steps = model, timestep_map, original_num_steps
-        self._maps = {}
+        self._maps = device_maps if device_maps is not None else {}
 
     def __call__(self, x, ts, **kwargs):
         key = (str(ts.device), ts.dtype)

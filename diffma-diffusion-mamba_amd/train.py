@@ -139,13 +139,20 @@ def main(args):
         ema = deepcopy(model).to(device)
     requires_grad(ema, False)
     model = model.to(device)
-    ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
-              bucket_cap_mb=64)
+    # graph_train: replay the whole optimisation step from a hipGraph (single process; pays off below ~100 samples per GPU,
+    # where the eager step is bound by the host's launch rate -- e.g. the reference's own global_batch_size of 8)
+    use_graph = bool(args.get("graph_train", False)) and world == 1 and device.type == "cuda" and int(args.accumulation_steps) == 1
+    if use_graph:
+        ddp = model                                  # one process: no reducer hooks inside the captured backward
+    else:
+        ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
+                  bucket_cap_mb=64)
     diffusion = create_diffusion(timestep_respacing="")
     logger.info(f"DiffMa Parameters: {sum(p.numel() for p in model.parameters()):,}")
     logger.info(f"Use half-precision training? {args.autocast}")
     lr = args.lr_ if args.init_from_pretrain_ckpt else args.lr
-    opt = torch.optim.AdamW(ddp.parameters(), lr=lr, weight_decay=0, fused=device.type == "cuda")
+    opt = torch.optim.AdamW(ddp.parameters(), lr=lr, weight_decay=0, fused=device.type == "cuda", capturable=use_graph)
+    graphed = None
 
     if not args.get("synthetic", False):
         raise RuntimeError("real-data training needs the SD-VAE / BiomedCLIP / CT_Encoder weights, which are not available "
@@ -167,22 +174,35 @@ def main(args):
         logger.info(f"Beginning epoch {epoch}...")
         for item, (z, y, y2, w) in enumerate(data.batches(local_batch, device, epoch, rank, world), 1):
             t = torch.randint(0, diffusion.num_timesteps, (z.shape[0],), device=device)
-            with torch.autocast(device.type, dtype=amp, enabled=amp is not None):
-                loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
-            bad = (~torch.isfinite(loss.detach())).float()
-            dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # every rank takes the same decision
-            loss.backward()                              # always run backward: keeps DDP's bucket all-reduces matched
-            if bad.item() > 0:
-                logger.info("nan......      ignore losses......")
-                opt.zero_grad(set_to_none=True)
-                continue
-            if train_steps % args.accumulation_steps == 0:
-                opt.step()
-                update_ema(ema, model)
-                opt.zero_grad(set_to_none=True)
-            running_loss += loss.item()
-            log_steps += 1
-            train_steps += 1
+            if use_graph:
+                if graphed is None:
+                    from .graphed import GraphedTrainStep
+                    graphed = GraphedTrainStep(model, ema, opt, diffusion, z, t, y, y2, w, autocast_dtype=amp, ema_decay=0.999)
+                loss = graphed.step(z, t, y, y2, w)             # forward, backward, AdamW and EMA in one replay
+                train_steps += 1
+                log_steps += 1
+                if train_steps % args.log_every == 0:           # the only host sync of the graphed loop
+                    lv = loss.item()
+                    if lv != lv:
+                        raise FloatingPointError(f"non-finite loss at step {train_steps} (a graphed step cannot skip its update)")
+                    running_loss = lv * log_steps               # the log line shows the latest loss instead of a running mean
+            else:
+                with torch.autocast(device.type, dtype=amp, enabled=amp is not None):
+                    loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
+                bad = (~torch.isfinite(loss.detach())).float()
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # every rank takes the same decision
+                loss.backward()                              # always run backward: keeps DDP's bucket all-reduces matched
+                if bad.item() > 0:
+                    logger.info("nan......      ignore losses......")
+                    opt.zero_grad(set_to_none=True)
+                    continue
+                if train_steps % args.accumulation_steps == 0:
+                    opt.step()
+                    update_ema(ema, model)
+                    opt.zero_grad(set_to_none=True)
+                running_loss += loss.item()
+                log_steps += 1
+                train_steps += 1
             if train_steps % args.log_every == 0:
                 if device.type == "cuda":
                     torch.cuda.synchronize()
@@ -215,6 +235,7 @@ def cli(argv=None):
     p.add_argument("--use-mamba2", action="store_true")
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning instead of datasets + frozen encoders")
     p.add_argument("--max-steps", type=int, default=None)
+    p.add_argument("--graph-train", action="store_true", help="replay the whole optimisation step from a hipGraph (1 GPU; for small batches)")
     p.add_argument("--config", type=str, required=True)
     a = p.parse_args(argv)
     over = {k: v for k, v in vars(a).items() if v is not None and k != "config"}
