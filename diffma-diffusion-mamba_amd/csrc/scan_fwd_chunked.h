@@ -1,5 +1,5 @@
 #pragma once
-// K1c  chunk-parallel forward scan for SMALL launches (sampling at batch 1..~40; no checkpoints).
+// K1c  chunk-parallel forward scan for SMALL launches (sampling and graphed small-batch training at batch 1..~10).
 //
 // The sequential kernel (scan_fwd_impl.h) needs nseq * dim/64 >= ~2000 waves to fill the chip; a p_sample step at
 // batch 8 launches 384, and every launch then costs the full 196-step dependent chain (~70 us, 38 % of a
@@ -17,7 +17,7 @@
 
 namespace dm {
 
-template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC, bool ASH = false>
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC, bool ASH = false, bool CKPT = false>
 __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan_fwd_args p) {
     constexpr int NP = N / 2;
     constexpr int ES = (int)sizeof(T);
@@ -46,6 +46,10 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
     const cptr<int32_t> oidx = IDX ? as_const(p.out_row_index + (int64_t)dir * L) : nullptr;
     const TBC* __restrict__ Bg = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
     const TBC* __restrict__ Cg = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
+    constexpr bool CK_PACKED = std::is_same<T, bf16_t>::value;
+    constexpr int CK_ROWS = CK_PACKED ? NP : N;
+    const int nck = (L + FWD_CKE - 1) / FWD_CKE;
+    const rsrc_t r_ck = make_rsrc(CKPT ? (const uint32_t*)p.ckpt + (int64_t)s * nck * CK_ROWS * p.dim : nullptr);
 
     // ---- this chunk's inputs: requested up front, kept in registers for both passes ------------------------------
     float uu[LC], dl[LC], zz[LC];
@@ -142,6 +146,20 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
             }
             const float y = scan_step<N, HAS_Z, false, ASH>(h, A2, Bc, Cc, uu[j], dl[j], zz[j], Dv, 0.0f);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
+            if (CKPT && (l + 1) % FWD_CKE == 0 && l + 1 < L) {          // training: the state entering every 4-step chunk (wave-uniform)
+                const int ci = (l + 1) / FWD_CKE;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    if constexpr (CK_PACKED) {
+                        uint32_t w;
+                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
+                        __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((ci * NP + k) * p.dim) * 4, 0);
+                    } else {
+                        bio<float>::st(r_ck, d * 4, ((ci * N + 2 * k) * p.dim) * 4, h[k].x);
+                        bio<float>::st(r_ck, d * 4, ((ci * N + 2 * k + 1) * p.dim) * 4, h[k].y);
+                    }
+                }
+            }
         }
     }
 }
@@ -155,23 +173,28 @@ static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
     static const int forced = [] { const char* e = getenv("DM_SCAN_CHUNKED"); return e ? atoi(e) : -1; }();   // 0 / 1: developer override
     if (forced == 0) return false;
     const int64_t waves = (int64_t)a.nseq * ((a.dim + WAVE - 1) / WAVE);
-    return !a.ckpt && !a.last_state && a.dstate == 16 && (waves <= 512 || forced == 1) && a.seqlen > 4 * CHUNKED_NW &&
+    if (a.ckpt && !(a.z && a.z_row_index && (a.flags & DM_FLAG_DELTA_SOFTPLUS))) return false;   // checkpoints: model call pattern only
+    return !a.last_state && a.dstate == 16 && (waves <= 512 || forced == 1) && a.seqlen > 4 * CHUNKED_NW &&
            a.seqlen <= CHUNKED_NW * CHUNKED_LC;
 }
 
 template <typename T, typename TBC, bool HAS_Z, bool IDX>
 static void launch_fwd_chunked2(const dm_scan_fwd_args& a, hipStream_t st) {
     dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq), block(WAVE * CHUNKED_NW);
-    if constexpr (HAS_Z && IDX) {
-        if ((a.flags & DM_FLAG_A_SHARED) && (a.flags & DM_FLAG_DELTA_SOFTPLUS)) {
-            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true>), grid, block, 0, st, a);
+    const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
+    if constexpr (HAS_Z && IDX) {                   // the model's call pattern: also built with checkpoints (small-batch training)
+        if ((a.flags & DM_FLAG_A_SHARED) && sp) {
+            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, false>), grid, block, 0, st, a);
+            return;
+        }
+        if (a.ckpt && sp) {
+            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, a);
             return;
         }
     }
-    if (a.flags & DM_FLAG_DELTA_SOFTPLUS)
-        hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, true, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, false, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
+    if (sp) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, true, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, false, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
 }
 
 template <typename T, typename TBC>

@@ -69,9 +69,12 @@ def test_scan_fwd_chunk_parallel_variant(gpu, dtype, L, Dm, with_z):
     zsrc = torch.randn(Bsz, L, Dm, generator=g).to(dtype) if with_z else None
     perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
     operms = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+    ckpt = None
     if with_z:
+        if dtype == torch.float32:                   # training form of the same launch: checkpoints every 4 steps from pass 2
+            ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_()
         out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zsrc.to(gpu), d["bias"], True,
-                               z_row_index=perms.to(gpu), out_row_index=operms.to(gpu), batch_per_dir=Bsz)
+                               z_row_index=perms.to(gpu), out_row_index=operms.to(gpu), batch_per_dir=Bsz, ckpt=ckpt)
     else:
         out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], None, d["bias"], True)
     torch.cuda.synchronize()
@@ -85,6 +88,13 @@ def test_scan_fwd_chunk_parallel_variant(gpu, dtype, L, Dm, with_z):
                                  host["D"].double(), z=zz, delta_bias=host["bias"].double(), delta_softplus=True)[0].T
         got = out[s][operms[k].long()] if with_z else out[s]
         torch.testing.assert_close(got.double(), ref, rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()))
+        if ckpt is not None and s in (0, S - 1):
+            K = hip_ops.SCAN_CKPT_EVERY
+            for c in (1, 3, 4, (L - 1) // K):        # incl. boundaries that fall inside and between the 14-step wave chunks
+                _, hl = selective_scan_ref(cm(host["u"])[..., :c * K], cm(host["delta"])[..., :c * K], host["A"].double(),
+                                           cm(host["B"])[..., :c * K], cm(host["C"])[..., :c * K], None, z=None,
+                                           delta_bias=host["bias"].double(), delta_softplus=True, return_last_state=True)
+                torch.testing.assert_close(ckpt[s, c].cpu().double().T, hl[0], rtol=1e-4, atol=1e-5 * max(1.0, hl.abs().max().item()))
 
 
 @pytest.mark.parametrize("softplus,with_z", [(False, True), (True, False), (False, False)])
