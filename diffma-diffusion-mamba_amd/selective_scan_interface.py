@@ -209,8 +209,9 @@ class _SpiralSSMFn(torch.autograd.Function):
         x_view, z_view = xz[..., :Din], xz[..., Din:]
         need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
         xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
-        x_dbl = F.linear(xc.view(-1, Din), Wx.to(dt_))                         # [ndir*B*L, R+2N]
-        delta = F.linear(x_dbl[:, :R], Wdt.to(dt_)).view(ndir * Bsz, L, Din)
+        Wx_c, Wdt_c = Wx.to(dt_), Wdt.to(dt_)                                  # kept for the backward (one cast per step, not two)
+        x_dbl = F.linear(xc.view(-1, Din), Wx_c)                               # [ndir*B*L, R+2N]
+        delta = F.linear(x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         ckpt = None
@@ -219,12 +220,12 @@ class _SpiralSSMFn(torch.autograd.Function):
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
                                 out_row_index=scan_index, batch_per_dir=Bsz, ckpt=ckpt)             # token order
         y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din))
-        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt)
+        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt = ctx.saved_tensors
+        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c = ctx.saved_tensors
         Bsz, L, D2 = xz.shape
         Din = D2 // 2
         ndir = scan_index.shape[0]
@@ -244,11 +245,11 @@ class _SpiralSSMFn(torch.autograd.Function):
             out_row_index=scan_index, batch_per_dir=Bsz,
             dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
-        dx_dbl[:, :R] = ddelta2 @ Wdt.to(dt_)      # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
+        dx_dbl[:, :R] = ddelta2 @ Wdt_c            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
-        dxc = du.view(M, Din).addmm_(dx_dbl, Wx.to(dt_)).view(ndir * Bsz, L, Din)
+        dxc = du.view(M, Din).addmm_(dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                row_index=scan_index, ndir=ndir, silu=True)
         dxz = torch.empty_like(xz)
