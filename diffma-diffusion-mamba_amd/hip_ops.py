@@ -206,8 +206,8 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
         + (scan_nchunk(L, ckpt_every) - 1) * S * (ckpt.shape[2] if ckpt is not None else N) * Dm * 4
     _launch("dm_selective_scan_bwd", a, u, nbytes)
-    if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype): reduce straight into the caller's buffer
-        torch.sum(dBC, dim=2, dtype=dbc_out.dtype, out=dbc_out)
+    if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype) in the caller's buffer: fp32 sum, ONE converting copy
+        dbc_out.copy_(dBC.sum(dim=2))           # (sum(..., dtype=bf16, out=) would first cast the whole partial tensor)
         dBCs = dbc_out
     else:
         dBCs = dBC.sum(dim=2)                   # [S, L, 2N] fp32, deterministic
