@@ -14,11 +14,7 @@ namespace dm {
 constexpr int LN_WAVES = 4;
 constexpr int LN_MAXE = 16;     // values per lane: C <= 64 * 16
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_dpp(v); }
 
 // element c of the logical row [x | x2]
 template <typename T>

@@ -147,4 +147,18 @@ __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // thread-local error string (host side)
 void set_error(const char* fmt, ...);
 
+// Sum over the 64 lanes of a wave on the VALU's DPP path (every lane gets the total): 4 in-row butterfly steps, two
+// row broadcasts and one readlane, instead of 6 ds_bpermute round trips through the LDS pipe (__shfl_xor).
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+#define DM_DPP_ADD(CTRL, ROWMASK) x += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), CTRL, ROWMASK, 0xF, true))
+    DM_DPP_ADD(0xB1, 0xF);        // quad_perm [1,0,3,2]   : lane ^ 1
+    DM_DPP_ADD(0x4E, 0xF);        // quad_perm [2,3,0,1]   : lane ^ 2
+    DM_DPP_ADD(0x141, 0xF);       // row_half_mirror       : the other quad of the 8
+    DM_DPP_ADD(0x140, 0xF);       // row_mirror            : the other half of the 16-lane row -> every lane = row total
+    DM_DPP_ADD(0x142, 0xA);       // row_bcast15 into rows 1, 3 : += total of the row below
+    DM_DPP_ADD(0x143, 0xC);       // row_bcast31 into rows 2, 3 : += total of rows 0..1
+#undef DM_DPP_ADD
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), 63));
+}
+
 }  // namespace dm

@@ -12,11 +12,7 @@ namespace dm {
 constexpr int RMS_WAVES = 4;
 constexpr int RMS_ROWS_PER_BLOCK = 32;
 
-__device__ __forceinline__ float rms_wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
+__device__ __forceinline__ float rms_wave_sum(float v) { return wave_sum_dpp(v); }
 
 template <typename T>
 __device__ __forceinline__ void rms_ld4(float (&dst)[4], const T* p) {
