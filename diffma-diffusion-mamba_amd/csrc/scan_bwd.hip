@@ -19,7 +19,7 @@ extern "C" int dm_selective_scan_bwd(const dm_scan_bwd_args* args, void* stream)
     if (a.nseq <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ngroups <= 0) { set_error("dm_selective_scan_bwd: non-positive size"); return DM_ERR_ARG; }
     if (a.nseq > 65535) { set_error("dm_selective_scan_bwd: nseq %d > 65535", a.nseq); return DM_ERR_ARG; }
     if (a.ckpt_every != BWD_SUB) { set_error("dm_selective_scan_bwd: ckpt_every must be %d", BWD_SUB); return DM_ERR_ARG; }
-    if (!a.ckpt && a.seqlen > BWD_SUB) { set_error("dm_selective_scan_bwd: ckpt required for seqlen > %d", BWD_SUB); return DM_ERR_ARG; }
+    if (!a.ckpt) { set_error("dm_selective_scan_bwd: ckpt (the checkpoints written by dm_selective_scan_fwd) is required"); return DM_ERR_ARG; }
     if (a.ckpt && a.ckpt_dtype != (a.io_dtype == DM_BF16 ? DM_BF16 : DM_F32)) {
         set_error("dm_selective_scan_bwd: ckpt_dtype must be DM_BF16 for bf16 I/O and DM_F32 otherwise"); return DM_ERR_DTYPE;
     }

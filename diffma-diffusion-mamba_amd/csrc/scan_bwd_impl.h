@@ -250,6 +250,42 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
     __syncthreads();
 
+    // state entering sub-chunk ci, as raw checkpoint words (packed checkpoints stay raw until they are used: unpacking
+    // at the load would put a vmcnt(0) right behind it).  Slot ci of the forward's checkpoints for 0 < 4 ci < L, slot 0
+    // (= the state after the last step) for 4 ci == L, zero for ci == 0 and past the end.
+    constexpr int H0W = CK_PACKED ? NPL : 2 * NPL;               // 32-bit words per state slice
+    auto load_state = [&](int ci, uint32_t(&w)[H0W]) {
+        const int slot = (ci > 0 && ci * SUB < L) ? ci : ((ci > 0 && ci * SUB == L) ? 0 : -1);      // wave-uniform
+        if (slot < 0) {
+#pragma unroll
+            for (int k = 0; k < H0W; ++k) w[k] = 0u;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                if constexpr (CK_PACKED) {
+                    w[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * (N / 2) + k) * p.dim) * 4, 0);
+                } else {
+                    w[2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k) * p.dim) * 4, 0);
+                    w[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k + 1) * p.dim) * 4, 0);
+                }
+            }
+        }
+    };
+    auto unpack_state = [&](f32x2(&h)[NPL], const uint32_t(&w)[H0W]) {
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            if constexpr (CK_PACKED) {
+                h[k].x = __uint_as_float(w[k] << 16);
+                h[k].y = __uint_as_float(w[k] & 0xffff0000u);
+            } else {
+                h[k].x = __uint_as_float(w[2 * k]);
+                h[k].y = __uint_as_float(w[2 * k + 1]);
+            }
+        }
+    };
+    uint32_t hnext[H0W];                                         // state entering the sub-chunk after the current chunk
+    load_state(nchunk * (CK / SUB), hnext);
+
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int l0 = ch * CK;
@@ -283,26 +319,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
         // ---- state slices entering the chunk's sub-chunks (sub-chunk 0 of the sequence and sub-chunks past the end: 0) ----
         // (packed checkpoints stay raw until the sub-chunk starts: unpacking here would put a vmcnt(0) right behind every load)
-        constexpr int H0W = CK_PACKED ? NPL : 2 * NPL;               // 32-bit words per sub-chunk state slice
         uint32_t h0w[CK / SUB][H0W];
 #pragma unroll
-        for (int sc = 0; sc < CK / SUB; ++sc) {
-            const int ci = ch * (CK / SUB) + sc;
-            if (ci == 0 || ci * SUB >= L) {
-#pragma unroll
-                for (int k = 0; k < H0W; ++k) h0w[sc][k] = 0u;
-            } else {
-#pragma unroll
-                for (int k = 0; k < NPL; ++k) {
-                    if constexpr (CK_PACKED) {
-                        h0w[sc][k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * (N / 2) + k) * p.dim) * 4, 0);
-                    } else {
-                        h0w[sc][2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * N + 2 * k) * p.dim) * 4, 0);
-                        h0w[sc][2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((ci * N + 2 * k + 1) * p.dim) * 4, 0);
-                    }
-                }
-            }
-        }
+        for (int sc = 0; sc < CK / SUB; ++sc) load_state(ch * (CK / SUB) + sc, h0w[sc]);
 
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
@@ -343,23 +362,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int sc = CK / SUB - 1; sc >= 0; --sc) {
             f32x2 h[NPL];
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                if constexpr (CK_PACKED) {
-                    h[k].x = __uint_as_float(h0w[sc][k] << 16);
-                    h[k].y = __uint_as_float(h0w[sc][k] & 0xffff0000u);
-                } else {
-                    h[k].x = __uint_as_float(h0w[sc][2 * k]);
-                    h[k].y = __uint_as_float(h0w[sc][2 * k + 1]);
-                }
-            }
+            unpack_state(h, h0w[sc]);
             f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
 #pragma unroll
                 for (int k = 0; k < NPL; ++k) hs[i][k] = h[k];
-                fwd_step(h, sc * SUB + i);
+                if (i < SUB - 1) fwd_step(h, sc * SUB + i);
             }
+            // the state after the sub-chunk's last step is the next sub-chunk's checkpoint: one recomputed step less
+            if (sc == CK / SUB - 1) unpack_state(h, hnext);
+            else unpack_state(h, h0w[sc == CK / SUB - 1 ? sc : sc + 1]);
             // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
 #pragma unroll
             for (int i = SUB - 1; i >= 0; --i) {
@@ -455,6 +468,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 }
             }
         }
+#pragma unroll
+        for (int k = 0; k < H0W; ++k) hnext[k] = h0w[0][k];
         __syncthreads();
         flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
             }
             const float y = scan_step<N, HAS_Z, false, ASH>(h, A2, Bc, Cc, uu[j], dl[j], zz[j], Dv, 0.0f);
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
-            if (CKPT && (l + 1) % FWD_CKE == 0 && l + 1 < L) {          // training: the state entering every 4-step chunk (wave-uniform)
-                const int ci = (l + 1) / FWD_CKE;
+            if (CKPT && ((l + 1) % FWD_CKE == 0 || l + 1 == L)) {       // training: the state entering every 4-step chunk (wave-uniform);
+                const int ci = (l + 1 < L) ? (l + 1) / FWD_CKE : 0;      // slot 0 = the state after the last step
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     if constexpr (CK_PACKED) {

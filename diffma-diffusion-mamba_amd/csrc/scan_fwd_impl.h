@@ -122,21 +122,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     constexpr int CK_ROWS = CK_PACKED ? NP : N;                     // 32-bit rows of [dim] per checkpoint
     const int nchunk = CKPT ? (L + FWD_CKE - 1) / FWD_CKE : 0;
     const rsrc_t r_ck = make_rsrc(CKPT ? (const uint32_t*)p.ckpt + (int64_t)s * nchunk * CK_ROWS * p.dim : nullptr);
-    auto store_ckpt = [&](int done) {                               // done = steps finished (wave-uniform)
-        if (done < L) {                                             // state entering chunk done / FWD_CKE
-            const int c = done / FWD_CKE;
+    auto store_slot = [&](int c) {
 #pragma unroll
-            for (int k = 0; k < NP; ++k) {
-                if constexpr (CK_PACKED) {
-                    uint32_t w;
-                    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
-                    __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((c * NP + k) * p.dim) * 4, 0);
-                } else {
-                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
-                    bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
-                }
+        for (int k = 0; k < NP; ++k) {
+            if constexpr (CK_PACKED) {
+                uint32_t w;
+                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
+                __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((c * NP + k) * p.dim) * 4, 0);
+            } else {
+                bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
+                bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
             }
         }
+    };
+    auto store_ckpt = [&](int done) {                               // done = steps finished (wave-uniform)
+        if (done < L) store_slot(done / FWD_CKE);                   // state entering chunk done / FWD_CKE
     };
 
     // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
@@ -230,6 +230,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
             if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l + 1);
         }
     }
+
+    if (CKPT) store_slot(0);                   // slot 0 (chunk 0 starts from zero) holds the state after the last step
 
     if (p.last_state) {
         float* ls = p.last_state + ((int64_t)s * N) * p.dim + d;

@@ -90,9 +90,10 @@ def test_scan_fwd_chunk_parallel_variant(gpu, dtype, L, Dm, with_z):
         torch.testing.assert_close(got.double(), ref, rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()))
         if ckpt is not None and s in (0, S - 1):
             K = hip_ops.SCAN_CKPT_EVERY
-            for c in (1, 3, 4, (L - 1) // K):        # incl. boundaries that fall inside and between the 14-step wave chunks
-                _, hl = selective_scan_ref(cm(host["u"])[..., :c * K], cm(host["delta"])[..., :c * K], host["A"].double(),
-                                           cm(host["B"])[..., :c * K], cm(host["C"])[..., :c * K], None, z=None,
+            for c in (0, 1, 3, 4, (L - 1) // K):     # incl. boundaries that fall inside and between the 14-step wave chunks; slot 0 = final state
+                n = c * K if c else L
+                _, hl = selective_scan_ref(cm(host["u"])[..., :n], cm(host["delta"])[..., :n], host["A"].double(),
+                                           cm(host["B"])[..., :n], cm(host["C"])[..., :n], None, z=None,
                                            delta_bias=host["bias"].double(), delta_softplus=True, return_last_state=True)
                 torch.testing.assert_close(ckpt[s, c].cpu().double().T, hl[0], rtol=1e-4, atol=1e-5 * max(1.0, hl.abs().max().item()))
 
@@ -144,9 +145,10 @@ def test_scan_fwd_row_index_and_checkpoints(gpu):
                                  delta_softplus=True)[0].T  # [L, Dm] in scan order
         got = out[s][operms[k].long()]  # row operm[l] holds step l
         torch.testing.assert_close(got.double(), ref, rtol=1e-4, atol=1e-5 * max(1.0, ref.abs().max().item()))
-        for c in range(1, nch):
-            _, hl = selective_scan_ref(cm(host["u"])[..., :c * K], cm(host["delta"])[..., :c * K], host["A"].double(),
-                                       cm(host["B"])[..., :c * K], cm(host["C"])[..., :c * K], None, z=None,
+        for c in range(0, nch):                    # slot 0 = the state after the last step, slot c > 0 = state entering step c*K
+            n = c * K if c else L
+            _, hl = selective_scan_ref(cm(host["u"])[..., :n], cm(host["delta"])[..., :n], host["A"].double(),
+                                       cm(host["B"])[..., :n], cm(host["C"])[..., :n], None, z=None,
                                        delta_bias=host["bias"].double(), delta_softplus=True, return_last_state=True)
             torch.testing.assert_close(ckpt[s, c].cpu().double().T, hl[0], rtol=1e-4, atol=1e-5 * max(1.0, hl.abs().max().item()))
 
