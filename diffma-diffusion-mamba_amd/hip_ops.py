@@ -145,7 +145,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     es = u.element_size()
     nbytes = 4 * S * Dm * L * es - (0 if z is not None else S * Dm * L * es) + 2 * S * N * L * Bm.element_size() + 4 * Dm * N + 8 * Dm
     if ckpt is not None:
-        nbytes += (scan_nchunk(L, ckpt_every) - 1) * S * ckpt.shape[2] * Dm * 4
+        nbytes += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * Dm * 4     # slots 1.. + slot 0 (the final state)
     _launch("dm_selective_scan_fwd", a, u, nbytes)
     return out
 
@@ -204,7 +204,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
     es = u.element_size()
     nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
-        + (scan_nchunk(L, ckpt_every) - 1) * S * (ckpt.shape[2] if ckpt is not None else N) * Dm * 4
+        + (scan_nchunk(L, ckpt_every) - 1 + (L % ckpt_every == 0)) * S * ckpt.shape[2] * Dm * 4   # slot 0 is read when L ends on a boundary
     _launch("dm_selective_scan_bwd", a, u, nbytes)
     if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype) in the caller's buffer: fp32 sum, ONE converting copy
         dbc_out.copy_(dBC.sum(dim=2))           # (sum(..., dtype=bf16, out=) would first cast the whole partial tensor)
