@@ -93,7 +93,8 @@ def cpu_baseline(args, tokens):
     gen = torch.Generator().manual_seed(0)
     b = synthetic_batch(1, tokens, "cpu", gen)
     depth, patch = net.depth, net.patch_size
-    model = lambda x, t, **kw: diffma_forward_ref(sd, x, t, kw["y"], kw["y2"], kw["w"], patch_size=patch, depth=depth, dtype=torch.float32)
+    model = lambda x, t, **kw: diffma_forward_ref(sd, x, t, kw["y"], kw["y2"], kw["w"], patch_size=patch, depth=depth, dtype=torch.float32,
+                                                  block_type=net.block_type)
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
         t = torch.randint(0, d.num_timesteps, (1,))

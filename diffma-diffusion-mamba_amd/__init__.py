@@ -6,8 +6,8 @@ the importable name onto this directory).  Layout:
   csrc/                       hand-written gfx950 HIP kernels + the C ABI (include/diffma_hip.h)
   _lib.py, hip_ops.py         ctypes binding and allocation-explicit launch wrappers
   selective_scan_interface.py reference-facing operators: selective_scan_fn, mamba_inner_fn, ...
-  mamba.py, mamba_block.py    Mamba mixer ('spiral') and Spiral_MambaBlock  (block/mamba.py, block/mamba_block.py)
-  model.py, tools.py          DiffMa, DiffMa_models, spiral()               (model.py, tools.py)
+  mamba.py, mamba_block.py    Mamba mixer ('spiral' + the baseline orders) and the blocks  (block/mamba.py, block/mamba_block.py)
+  model.py, tools.py          DiffMa, DiffMa_models, spiral(), zig(), vmamba_()            (model.py, tools.py)
   diffusion/                  create_diffusion / GaussianDiffusion           (diffusion/*)
 """
 __version__ = "0.1.0"

@@ -1,4 +1,5 @@
-"""Mamba-1 mixer of DiffMa, 'spiral' scan (reference block/mamba.py:226-355), MI355X-native.
+"""Mamba-1 mixer of DiffMa, 'spiral' scan (reference block/mamba.py:226-355), MI355X-native; the scan orders of the
+baseline blocks ('zigma', 'vim', 'vmamba', 'eff': block/mamba.py:85-224, 357-401) run on the same fused operator.
 
 State-dict keys and constructor arguments match the reference class so its checkpoints load:
     in_proj.weight (2*Din, d_model)   conv1d.weight (Din, 1, d_conv)   conv1d.bias (Din)
@@ -18,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .selective_scan_interface import linear_splitk, spiral_ssm
+from .tools import efficient_scan_tokens
 
 
 class Mamba(nn.Module):
@@ -59,20 +61,53 @@ class Mamba(nn.Module):
 
         self.token_list, self.token_list_reversal = list(token_list), list(token_list_reversal)
         self.origina_list, self.origina_list_reversal = list(origina_list), list(origina_list_reversal)
-        L = len(self.token_list)
-        if L:
+        # token_list is one permutation (spiral, zigma) or a list of four (vmamba, reference model.py:182-186)
+        nested = bool(self.token_list) and isinstance(self.token_list[0], (list, tuple))
+        L = len(self.token_list[0]) if nested else len(self.token_list)
+        if L and not nested and self.token_list_reversal:
             idx = torch.tensor([list(range(L)), self.token_list, self.token_list_reversal], dtype=torch.int32)
         else:
             idx = torch.zeros((3, 0), dtype=torch.int32)
         # not in the state dict (the reference keeps Python lists)
         self.register_buffer("scan_index", idx, persistent=False)
+        self._tables = {}                  # (scan_type, L, device) -> index tensors of the baseline scan orders
+        self.vim_flip = "reference"        # 'reference': flip the feature axis of the backward output (block/mamba.py:366,
+                                           # the token order stays reversed); 'token': the intended flip
+
+    def _baseline_tables(self, scan_type, L, device):
+        key = (scan_type, L, str(device))
+        tab = self._tables.get(key)
+        if tab is not None:
+            return tab
+        i32 = lambda rows: torch.tensor(rows, dtype=torch.int32, device=device)
+        if scan_type == "zigma":                                   # one permutation per block (block/mamba.py:357-360)
+            tab = (i32([self.token_list]), None)
+        elif scan_type == "vmamba":                                # four permutations, outputs summed (block/mamba.py:369-382)
+            tab = (i32(self.token_list), None)
+        elif scan_type == "vim":                                   # forward + time-reversed scan (block/mamba.py:362-367)
+            fwd, rev = list(range(L)), list(range(L - 1, -1, -1))
+            tab = (i32([fwd, rev]), i32([fwd, fwd]) if self.vim_flip == "reference" else None)
+        elif scan_type == "eff":                                   # four atrous sub-grids of L/4 tokens (block/mamba.py:384-399)
+            n = int(round(math.sqrt(L)))
+            if n * n != L:
+                raise ValueError(f"EfficientVMamba needs a square token grid, got L={L}")
+            tok = torch.from_numpy(efficient_scan_tokens(n)).reshape(-1)
+            inv = torch.empty_like(tok)
+            inv[tok] = torch.arange(L)
+            tab = (i32([list(range(L // 4))]), (tok.to(device), inv.to(device)))
+        else:
+            raise NotImplementedError(f"scan_type={scan_type!r}")
+        if tab[0].shape[1] != (L // 4 if scan_type == "eff" else L):
+            raise ValueError(f"sequence length {L} != scan table length {tab[0].shape[1]}")
+        self._tables[key] = tab
+        return tab
 
     def forward(self, hidden_states, scan_type="spiral", inference_params=None):
         """hidden_states: (B, L, d_model) -> (B, L, d_model)."""
-        if scan_type != "spiral":
-            raise NotImplementedError(f"scan_type={scan_type!r}: only the DiffMa 'spiral' path is built (SURVEY.md 8f)")
         if inference_params is not None:
             raise NotImplementedError("autoregressive decode is never used by a diffusion model")
+        if scan_type != "spiral":
+            return self._forward_baseline(hidden_states, scan_type)
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
@@ -87,3 +122,32 @@ class Mamba(nn.Module):
         y = spiral_ssm(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                        self.dt_proj.bias, A, self.D, self.scan_index)
         return linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)
+
+    def _forward_baseline(self, hidden_states, scan_type):
+        """The ZigMa / ViM / VMamba / EfficientVMamba token orders (reference block/mamba.py:357-401) on the fused operator.
+        The reference runs one mamba_inner_fn (conv .. out_proj) per direction and combines the projected outputs; out_proj is
+        linear and has no bias here, so the directions are summed before ONE projection wherever the reference sums them."""
+        Bsz, L, _ = hidden_states.shape
+        gather, extra = self._baseline_tables(scan_type, L, hidden_states.device)
+        xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
+        A = -torch.exp(self.A_log.float())
+        ssm = lambda inp, **kw: spiral_ssm(inp, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
+                                           self.dt_proj.bias, A, self.D, gather, **kw)
+        proj = lambda y: linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)
+        ndir = gather.shape[0]
+        if self.out_proj.bias is not None and ndir > 1 and scan_type != "vim":
+            raise NotImplementedError("out_proj bias with summed directions (the reference adds it once per direction)")
+        if scan_type in ("zigma", "vmamba"):
+            return proj(ssm(xz))
+        if scan_type == "vim":
+            if extra is None:                                      # vim_flip == 'token': average of the two scans, both in token order
+                return proj(ssm(xz) * 0.5) if self.out_proj.bias is None else proj(ssm(xz)) * 0.5 + 0.5 * self.out_proj.bias
+            ydir = ssm(xz, out_index=extra, merge=False)           # [2, B, L, Din]; direction 1 stays in reversed token order
+            return (proj(ydir[0]) + torch.flip(proj(ydir[1]), [2])) / 2      # literal block/mamba.py:366-367
+        # 'eff': every token belongs to exactly one of four L/4-token scans; gather them into a 4B batch and scatter back
+        tok, inv = extra
+        L4 = L // 4
+        sub = xz[:, tok].view(Bsz, 4, L4, xz.shape[-1]).transpose(0, 1).reshape(4 * Bsz, L4, xz.shape[-1])
+        out = proj(ssm(sub.contiguous()))                          # [4B, L/4, d_model]
+        out = out.view(4, Bsz, L4, -1).transpose(0, 1).reshape(Bsz, L, -1)
+        return out[:, inv]

@@ -1,4 +1,5 @@
-"""Spiral_MambaBlock: the DiffMa block (reference block/mamba_block.py:13-130).
+"""Spiral_MambaBlock: the DiffMa block (reference block/mamba_block.py:13-130), and the four baseline blocks the reference
+reproduces from other papers on the same mixer (ZigMa, ViM, VMamba, EfficientVMamba: block/mamba_block.py:132-398).
 
     shift, scale, gate = adaLN(c)                    x_ssm = LN(x)*(1+scale)+shift
     w_ssm = x_ssm * w   (soft mask, w in (0,1))      x_ssm = mamba1(x_ssm); w_ssm = mamba2(w_ssm)
@@ -70,3 +71,69 @@ class Spiral_MambaBlock(nn.Module):
         w_ssm = self.mamba2(w_ssm, "spiral")
         a = self.attention_network(torch.cat([x_ssm, w_ssm], dim=-1))
         return x + gate.unsqueeze(1) * (a * x_ssm + (1 - a) * w_ssm)
+
+
+class _BaselineMambaBlock(nn.Module):
+    """adaLN -> LN/modulate -> ONE mixer with the block's scan order -> gated residual (reference block/mamba_block.py:
+    190-198, 247-255, 318-326, 381-389: the four forward() bodies differ only in the scan type).  `w` (the soft mask) is
+    accepted and ignored, as in the reference.  Sub-module names equal the reference's (norm1, adaLN_modulation, mamba)."""
+    scan_type = None
+    mixer_first = False
+
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2=False, token_list=(), origina_list=()):
+        super().__init__()
+        if use_mamba2:
+            raise NotImplementedError("the baseline blocks are built on the Mamba-1 mixer only (SURVEY.md A.4-7: the reference's "
+                                      "Mamba-2 twins are partly broken)")
+        self.D_dim, self.E_dim, self.dt_rank, self.dim_inner, self.d_state = D_dim, E_dim, dt_rank, dim_inner, d_state
+        self.token_list, self.origina_list = token_list, origina_list
+        mixer = lambda: Mamba(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, token_list=token_list, origina_list=origina_list)
+        if self.mixer_first:                   # registration order = state-dict key order of the reference class
+            self.mamba = mixer()
+        self.norm1 = nn.LayerNorm(D_dim)
+        self.adaLN_modulation = nn.Sequential(nn.SiLU(), nn.Linear(2 * D_dim, 3 * D_dim, bias=True))
+        if not self.mixer_first:
+            self.mamba = mixer()
+        self.initialize_weights()
+
+    def initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def forward(self, x, c, w=None):
+        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        x_ssm = self.mamba(modulate(self.norm1(x), shift, scale), self.scan_type)
+        return x + gate.unsqueeze(1) * x_ssm
+
+
+class Zig_MambaBlock(_BaselineMambaBlock):
+    scan_type = "zigma"
+
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, token_list, origina_list, use_mamba2=False):
+        super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2, token_list, origina_list)
+
+
+class ViM_MambaBlock(_BaselineMambaBlock):
+    scan_type = "vim"
+    mixer_first = True
+
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2=False):
+        super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2)
+
+
+class VMamba_MambaBlock(_BaselineMambaBlock):
+    scan_type = "vmamba"
+    mixer_first = True
+
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, token_list, origina_list, use_mamba2=False):
+        super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2, token_list, origina_list)
+
+
+class EfficientVMamba_MambaBlock(_BaselineMambaBlock):
+    scan_type = "eff"
+
+    def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2=False):
+        super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2)

@@ -12,8 +12,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .mamba_block import Spiral_MambaBlock, modulate
-from .tools import spiral
+from .mamba_block import (EfficientVMamba_MambaBlock, Spiral_MambaBlock, ViM_MambaBlock, VMamba_MambaBlock, Zig_MambaBlock,
+                          modulate)
+from .tools import spiral, vmamba_, zig
 
 
 def _pair(v):
@@ -91,8 +92,9 @@ class DiffMa(nn.Module):
     def __init__(self, input_size=28, patch_size=2, strip_size=2, in_channels=4, hidden_size=512, depth=16,
                  learn_sigma=True, block_type="spiral", dt_rank=16, d_state=16, use_mamba2=False):
         super().__init__()
-        if block_type != "spiral":
-            raise NotImplementedError(f"block_type={block_type!r}: only the DiffMa spiral block is built (SURVEY.md 8f-3)")
+        if block_type not in ("spiral", "zig", "vim", "vmamba", "efficientVMamba"):
+            raise NotImplementedError(f"block_type={block_type!r}: the Mamba blocks are built (spiral, zig, vim, vmamba, "
+                                      "efficientVMamba); the attention baseline 'DiT' is not on the scan path (SURVEY.md 8f)")
         self.learn_sigma, self.depth, self.in_channels = learn_sigma, depth, in_channels
         self.out_channels = in_channels * 2 if learn_sigma else in_channels
         self.patch_size, self.input_size, self.block_type = patch_size, input_size, block_type
@@ -100,14 +102,25 @@ class DiffMa(nn.Module):
         self.t_embedder = TimestepEmbed(hidden_size)
         num_patches = self.x_embedder.num_patches
         self.pos_embed = nn.Parameter(torch.zeros(1, num_patches, hidden_size), requires_grad=False)
-        orders, inverses = spiral(int(input_size / patch_size))
-        nlist = len(orders)
-        self.blocks = nn.ModuleList([
-            Spiral_MambaBlock(D_dim=hidden_size, E_dim=2 * hidden_size, dim_inner=2 * hidden_size, dt_rank=dt_rank,
-                              d_state=d_state, use_mamba2=use_mamba2,
-                              token_list=orders[(2 * i) % nlist], token_list_reversal=orders[(2 * i) % nlist + 1],
-                              origina_list=inverses[(2 * i) % nlist], origina_list_reversal=inverses[(2 * i) % nlist + 1])
-            for i in range(depth)])
+        side = int(input_size / patch_size)
+        common = dict(D_dim=hidden_size, E_dim=2 * hidden_size, dim_inner=2 * hidden_size, dt_rank=dt_rank, d_state=d_state,
+                      use_mamba2=use_mamba2)
+        if block_type == "spiral":
+            orders, inverses = spiral(side)
+            nlist = len(orders)
+            blocks = [Spiral_MambaBlock(token_list=orders[(2 * i) % nlist], token_list_reversal=orders[(2 * i) % nlist + 1],
+                                        origina_list=inverses[(2 * i) % nlist], origina_list_reversal=inverses[(2 * i) % nlist + 1],
+                                        **common) for i in range(depth)]
+        elif block_type == "zig":             # block i scans in zigzag variant i % 8 (reference model.py:159-170)
+            blocks = [Zig_MambaBlock(token_list=zig(side, i)[0], origina_list=zig(side, i)[1], **common) for i in range(depth)]
+        elif block_type == "vim":             # forward + backward raster scans (model.py:171-180)
+            blocks = [ViM_MambaBlock(**common) for _ in range(depth)]
+        elif block_type == "vmamba":          # the same four scans in every block (model.py:181-193)
+            order_list, original_list = vmamba_(side)
+            blocks = [VMamba_MambaBlock(token_list=order_list, origina_list=original_list, **common) for _ in range(depth)]
+        else:                                 # 'efficientVMamba': four atrous sub-grid scans (model.py:194-203)
+            blocks = [EfficientVMamba_MambaBlock(**common) for _ in range(depth)]
+        self.blocks = nn.ModuleList(blocks)
         self.final_layer = FinalLayer(hidden_size, patch_size, self.out_channels)
         self.initialize_weights()
 
@@ -190,11 +203,18 @@ def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=
 _DEPTH = {"S": 4, "B": 8, "L": 16, "XL": 28, "XXL": 56}
 
 
-def _make(depth, patch):
+def _make(depth, patch, block_type="spiral"):
     def ctor(**kwargs):
-        return DiffMa(depth=depth, hidden_size=512, patch_size=patch, strip_size=patch, block_type="spiral", **kwargs)
+        return DiffMa(depth=depth, hidden_size=512, patch_size=patch, strip_size=patch, block_type=block_type, **kwargs)
     return ctor
 
 
 # 'DiffMa-{S,B,L,XL,XXL}/{2,4,7}'  (reference model.py:636-640)
 DiffMa_models = {f"DiffMa-{size}/{patch}": _make(depth, patch) for size, depth in _DEPTH.items() for patch in (2, 4, 7)}
+# the baseline families the reference reproduces on the same mixer: '{ZigMa,ViM,VMamba,EMamba}-{S,B,L,XL}/{2,4,7}' and
+# '-BL/2' (depth 13)  (reference model.py:641-664)
+for _family, _bt in (("ZigMa", "zig"), ("ViM", "vim"), ("VMamba", "vmamba"), ("EMamba", "efficientVMamba")):
+    for _size in ("S", "B", "L", "XL"):
+        for _patch in (2, 4, 7):
+            DiffMa_models[f"{_family}-{_size}/{_patch}"] = _make(_DEPTH[_size], _patch, _bt)
+    DiffMa_models[f"{_family}-BL/2"] = _make(13, 2, _bt)

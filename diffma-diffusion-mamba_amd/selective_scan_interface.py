@@ -199,7 +199,10 @@ class _SpiralSSMFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, grad_on=True):
+    def forward(ctx, xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, grad_on=True, out_index=None, merge=True):
+        """out_index (default: scan_index): row of the per-direction output that step l's result is written to -- the
+        baseline blocks need a scatter that is not the gather's inverse (ViM, block/mamba.py:362-367).  merge=False returns
+        the per-direction outputs [ndir, B, L, Din] instead of their sum."""
         Bsz, L, D2 = xz.shape
         Din = D2 // 2
         ndir = scan_index.shape[0]
@@ -217,15 +220,18 @@ class _SpiralSSMFn(torch.autograd.Function):
         ckpt = None
         if need_grad:
             ckpt = hip_ops.alloc_scan_ckpt(ndir * Bsz, L, N, Din, xz.dtype, xz.device)
+        oidx = scan_index if out_index is None else out_index
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
-                                out_row_index=scan_index, batch_per_dir=Bsz, ckpt=ckpt)             # token order
-        y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din))
-        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c)
-        return y
+                                out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt)                   # token order
+        ctx.merge = merge
+        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx)
+        if not merge:
+            return ydir.view(ndir, Bsz, L, Din)
+        return hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din)) if ndir > 1 else ydir
 
     @staticmethod
     def backward(ctx, dy):
-        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c = ctx.saved_tensors
+        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx = ctx.saved_tensors
         Bsz, L, D2 = xz.shape
         Din = D2 // 2
         ndir = scan_index.shape[0]
@@ -235,6 +241,8 @@ class _SpiralSSMFn(torch.autograd.Function):
         dy = dy.contiguous()
         if dy.dtype != dt_:
             dy = dy.to(dt_)
+        if not ctx.merge:
+            dy = dy.view(ndir * Bsz, L, Din)           # one gradient per direction
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         z_view = xz[..., Din:]
@@ -242,7 +250,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         dx_dbl = torch.empty((M, R + 2 * N), dtype=dt_, device=xz.device)
         du, ddelta, dz, _, _, dA, dD, dbias = hip_ops.scan_bwd(
             xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
-            out_row_index=scan_index, batch_per_dir=Bsz,
+            out_row_index=oidx, batch_per_dir=Bsz, dout_per_seq=not ctx.merge,
             dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
         dx_dbl[:, :R] = ddelta2 @ Wdt_c            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
@@ -256,7 +264,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
         hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
         return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
-                dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None, None)
+                dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -472,15 +480,16 @@ def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias
     return y
 
 
-def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, scan_index):
-    """Fused CrossScan -> 3x(conv1d+SiLU, x_proj, dt_proj, selective scan) -> CrossMerge (pre out_proj).
+def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, scan_index, out_index=None, merge=True):
+    """Fused CrossScan -> ndir x (conv1d+SiLU, x_proj, dt_proj, selective scan) -> CrossMerge (pre out_proj).
 
     xz: [B, L, 2*Din] token-major (the in_proj output); A: [Din, N] fp32 (= -exp(A_log));
-    scan_index: int32 [ndir, L] device tensor.  Returns y [B, L, Din]; the caller applies out_proj.
+    scan_index: int32 [ndir, L] device tensor (3 spiral directions for DiffMa; 1 / 2 / 4 for the baseline blocks).
+    out_index / merge: see _SpiralSSMFn.forward.  Returns y [B, L, Din] (or [ndir, B, L, Din]); the caller applies out_proj.
     """
     with torch.autocast(device_type="cuda", enabled=False):
         return _SpiralSSMFn.apply(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b.float(), A.float(), Dskip.float(),
-                                  scan_index, torch.is_grad_enabled())
+                                  scan_index, torch.is_grad_enabled(), out_index, merge)
 
 
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,

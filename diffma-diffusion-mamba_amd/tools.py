@@ -61,3 +61,46 @@ def spiral(n: int):
     """Same return convention as the reference: two lists of 16 Python lists."""
     orders, inverses = spiral_arrays(n)
     return [row.tolist() for row in orders], [row.tolist() for row in inverses]
+
+
+# ------------------------------------------------------------------------------------------------
+# Scan orders of the baseline blocks (reference tools.py:46-152)
+# ------------------------------------------------------------------------------------------------
+def _zig_rank(n: int, variant: int) -> np.ndarray:
+    """rank[r*n + c] of the reference's zig<variant>(n) matrix (0-based), variant in 1..8.
+
+    zig1 numbers the cells row by row, every other row right-to-left (a boustrophedon); zig2 does the same column by
+    column.  The other six are mirror images: 3/4 mirror the columns, 5/6 the rows, 7/8 both (tools.py:46-100)."""
+    r, c = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    if variant in (3, 4, 7, 8):
+        c = n - 1 - c
+    if variant in (5, 6, 7, 8):
+        r = n - 1 - r
+    if variant % 2 == 1:                                   # rows first
+        rank = r * n + np.where(r % 2 == 0, c, n - 1 - c)
+    else:                                                  # columns first
+        rank = c * n + np.where(c % 2 == 0, r, n - 1 - r)
+    return rank.reshape(-1).astype(np.int64)
+
+
+def zig(n: int, i: int):
+    """(rearrange_list, original_order_indexes) of ZigMa block i (reference tools.py:102-128): variant i % 8, with 0 -> 8."""
+    order = _zig_rank(n, i % 8 if i % 8 else 8)
+    return order.tolist(), np.argsort(order, kind="stable").tolist()
+
+
+def vmamba_(n: int):
+    """(order_list, original_list): the four VMamba scan orders zig1, zig2, zig7, zig8 and their inverses (tools.py:130-152)."""
+    orders = [_zig_rank(n, v) for v in (1, 2, 7, 8)]
+    return [o.tolist() for o in orders], [np.argsort(o, kind="stable").tolist() for o in orders]
+
+
+def efficient_scan_tokens(n: int) -> np.ndarray:
+    """[4, (n/2)^2] raster token ids visited by the four atrous scans of EfficientVMamba (block/mamba.py:169-180):
+    (even rows, even cols) row-major; (odd rows, even cols) column-major; (even rows, odd cols) row-major;
+    (odd rows, odd cols) column-major.  Each token belongs to exactly one scan; n must be even."""
+    if n % 2:
+        raise ValueError("EfficientVMamba's 2x2 atrous split needs an even token grid (the reference fails for odd n too)")
+    tok = np.arange(n * n).reshape(n, n)
+    return np.stack([tok[::2, ::2].reshape(-1), tok.T[::2, 1::2].reshape(-1), tok[::2, 1::2].reshape(-1),
+                     tok.T[1::2, 1::2].reshape(-1)]).astype(np.int64)

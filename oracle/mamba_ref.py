@@ -156,3 +156,70 @@ def mamba_spiral_forward_ref(hidden, params, lists, dtype=torch.float64):
             params["D"], delta_bias=params["dt_proj.bias"], delta_softplus=True, dtype=dtype))
     out = cross_merge_ref(torch.stack(outs, dim=1), orig, orig_rev)
     return out.to(out_dtype)
+
+
+# ---- baseline scan orders (block/mamba.py:85-224 reindexing, 357-401 call pattern) ---------------------------------
+def zig_lists_ref(n, i):
+    """Independent restatement of tools.zig (reference tools.py:46-128): boustrophedon numbering of the n x n grid, by rows
+    (odd variants) or columns (even), mirrored left-right (3, 4, 7, 8) and/or top-bottom (5..8).  Returns (order, inverse)."""
+    v = i % 8 or 8
+    order = []
+    for r in range(n):
+        for c in range(n):
+            rr = n - 1 - r if v >= 5 else r
+            cc = n - 1 - c if v in (3, 4, 7, 8) else c
+            if v % 2 == 1:
+                order.append(rr * n + (cc if rr % 2 == 0 else n - 1 - cc))
+            else:
+                order.append(cc * n + (rr if cc % 2 == 0 else n - 1 - rr))
+    inv = [0] * (n * n)
+    for pos, tok in enumerate(order):
+        inv[tok] = pos
+    return order, inv
+
+
+def vmamba_lists_ref(n):
+    """tools.vmamba_ (reference tools.py:130-152): zigzag variants 1, 2, 7, 8."""
+    pairs = [zig_lists_ref(n, v) for v in (1, 2, 7, 8)]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+def mamba_baseline_forward_ref(hidden, params, scan_type, lists=None, dtype=torch.float64):
+    """Mamba.forward(hidden, scan_type) for scan_type in 'zigma' | 'vim' | 'vmamba' | 'eff' (block/mamba.py:357-401) as a
+    pure function; one mamba_inner_ref (conv .. out_proj) per direction, combined exactly as the reference combines them.
+    lists: (order, inverse) for 'zigma', (orders[4], inverses[4]) for 'vmamba', None otherwise."""
+    out_dtype = hidden.dtype
+    hs = hidden.to(dtype)
+    xz = torch.einsum("ed,bld->bel", params["in_proj.weight"].to(dtype), hs)          # (B, 2Din, L)
+    A = -torch.exp(params["A_log"].to(torch.float64 if dtype == torch.float64 else torch.float32))
+    inner = lambda t: mamba_inner_ref(t, params["conv1d.weight"], params["conv1d.bias"], params["x_proj.weight"],
+                                      params["dt_proj.weight"], params["out_proj.weight"], None, A, None, None, params["D"],
+                                      delta_bias=params["dt_proj.bias"], delta_softplus=True, dtype=dtype)
+    lt = lambda v: torch.as_tensor(v, dtype=torch.long)
+    if scan_type == "zigma":                                   # gather by `order`, scatter back by its inverse (:357-360)
+        order, inv = lists
+        out = inner(xz[:, :, lt(order)])[:, lt(inv), :]
+    elif scan_type == "vim":                                   # (:362-367) the second output is flipped along dim 2 of a
+        out1 = inner(xz)                                       # (B, L, D) tensor, i.e. along the FEATURE axis (SURVEY.md A.4-6)
+        out2 = inner(torch.flip(xz, [2]))
+        out = (out1 + torch.flip(out2, [2])) / 2
+    elif scan_type == "vmamba":                                # (:369-382) four gathers, four scatters, sum
+        orders, invs = lists
+        out = sum(inner(xz[:, :, lt(orders[k])])[:, lt(invs[k]), :] for k in range(4))
+    elif scan_type == "eff":                                   # (:384-399) 2x2 atrous split of the token grid
+        Bsz, _, L = xz.shape
+        n = int(round(L ** 0.5))
+        grid = xz.reshape(Bsz, -1, n, n)                       # [.., row, col]
+        gt = grid.transpose(2, 3)                              # [.., col, row]
+        subs = [grid[:, :, ::2, ::2], gt[:, :, ::2, 1::2], grid[:, :, ::2, 1::2], gt[:, :, 1::2, 1::2]]
+        outs = [inner(sb.reshape(Bsz, xz.shape[1], -1)) for sb in subs]           # each (B, L/4, d_model)
+        h = n // 2
+        full = outs[0].new_empty(Bsz, n, n, outs[0].shape[-1])
+        full[:, ::2, ::2] = outs[0].reshape(Bsz, h, h, -1)
+        full[:, 1::2, ::2] = outs[1].reshape(Bsz, h, h, -1).transpose(1, 2)
+        full[:, ::2, 1::2] = outs[2].reshape(Bsz, h, h, -1)
+        full[:, 1::2, 1::2] = outs[3].reshape(Bsz, h, h, -1).transpose(1, 2)
+        out = full.reshape(Bsz, L, -1)
+    else:
+        raise ValueError(scan_type)
+    return out.to(out_dtype)

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from .mamba2_ref import mamba2_spiral_forward_ref
-from .mamba_ref import mamba_spiral_forward_ref
+from .mamba_ref import mamba_baseline_forward_ref, mamba_spiral_forward_ref, vmamba_lists_ref, zig_lists_ref
 
 
 def spiral_lists_ref(n):
@@ -57,8 +57,10 @@ def _timestep_embedding(t, dim, max_period=10000):
 
 
 def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.float32, return_blocks=False, use_mamba2=False,
-                       headdim=64):
-    """sd: reference-format state dict (tensors).  Inputs as DiffMa.forward (model.py:264)."""
+                       headdim=64, block_type="spiral"):
+    """sd: reference-format state dict (tensors).  Inputs as DiffMa.forward (model.py:264).
+    block_type: 'spiral' (DiffMa) or one of the baseline blocks 'zig' | 'vim' | 'vmamba' | 'efficientVMamba'
+    (block/mamba_block.py:190-198, 247-255, 318-326, 381-389; pinned by tests/golden/g9_baseline_blocks.npz)."""
     g = lambda k: sd[k].to(dtype)
     x = x.to(dtype)
     p = patch_size
@@ -85,8 +87,14 @@ def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.flo
         mod = F.linear(F.silu(c), g(pre + "adaLN_modulation.1.weight"), g(pre + "adaLN_modulation.1.bias"))
         shift, scale, gate = mod.chunk(3, dim=1)
         xs = _ln(inp, g(pre + "norm1.weight"), g(pre + "norm1.bias")) * (1 + scale[:, None]) + shift[:, None]
-        ws = xs * w
         sub = lambda name: {kk[len(pre + name) + 1:]: v for kk, v in sd.items() if kk.startswith(pre + name + ".")}
+        if block_type != "spiral":                       # one mixer, no soft mask, no fusion
+            scan_type = {"zig": "zigma", "vim": "vim", "vmamba": "vmamba", "efficientVMamba": "eff"}[block_type]
+            bl = zig_lists_ref(n_side, i) if block_type == "zig" else (vmamba_lists_ref(n_side) if block_type == "vmamba" else None)
+            h = inp + gate[:, None] * mamba_baseline_forward_ref(xs, sub("mamba"), scan_type, bl, dtype=dtype)
+            outs.append(h)
+            continue
+        ws = xs * w
         if use_mamba2:
             mix = lambda name, inp_: mamba2_spiral_forward_ref(inp_, sub(name), lists, headdim=headdim, dtype=dtype)
         else:

@@ -160,8 +160,15 @@ def test_product_model_has_reference_state_dict_layout():
 def test_factory_names_and_depths():
     from diffma_amd.model import DiffMa_models
 
-    assert len(DiffMa_models) == 15
-    assert {k.split("/")[0] for k in DiffMa_models} == {"DiffMa-S", "DiffMa-B", "DiffMa-L", "DiffMa-XL", "DiffMa-XXL"}
+    ours = [k for k in DiffMa_models if k.startswith("DiffMa-")]
+    assert len(ours) == 15
+    assert {k.split("/")[0] for k in ours} == {"DiffMa-S", "DiffMa-B", "DiffMa-L", "DiffMa-XL", "DiffMa-XXL"}
+    # the baseline families on the same mixer (reference model.py:641-664): 4 sizes x 3 patches + the depth-13 'BL/2' each
+    for fam, bt in (("ZigMa", "zig"), ("ViM", "vim"), ("VMamba", "vmamba"), ("EMamba", "efficientVMamba")):
+        assert len([k for k in DiffMa_models if k.startswith(fam + "-")]) == 13
+        b = DiffMa_models[f"{fam}-S/7"](input_size=28)
+        assert b.block_type == bt and b.depth == 4
+    assert len(DiffMa_models) == 15 + 4 * 13
     m = DiffMa_models["DiffMa-S/7"](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
     assert m.depth == 4 and m.x_embedder.num_patches == 16
     assert m.blocks[0].mamba1.dt_rank == 32                           # YAML dt_rank is ignored
@@ -271,3 +278,64 @@ def test_ct_encoder_matches_reference(tag, img, patch, emb):
         w, y2 = ct(torch.from_numpy(g[tag + ".x"]))
     torch.testing.assert_close(w, torch.from_numpy(g[tag + ".w"]), rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(y2, torch.from_numpy(g[tag + ".y2"]), rtol=1e-5, atol=2e-5)
+
+
+# ---- G9: baseline scan orders and blocks ----------------------------------------------------------------
+@pytest.mark.parametrize("n", [4, 7, 14])
+def test_baseline_scan_orders_match_reference(n):
+    """integer work: bit-exact, product tables and oracle restatement alike"""
+    from diffma_amd.tools import efficient_scan_tokens, vmamba_, zig
+    from oracle.mamba_ref import vmamba_lists_ref, zig_lists_ref
+
+    g = load("g9_baseline_blocks.npz")
+    for i in range(9):
+        for impl in (zig, zig_lists_ref):
+            order, inv = impl(n, i)
+            assert np.array_equal(np.asarray(order, dtype=np.int32), g[f"zig_{n}_{i}.order"])
+            assert np.array_equal(np.asarray(inv, dtype=np.int32), g[f"zig_{n}_{i}.inverse"])
+    for impl in (vmamba_, vmamba_lists_ref):
+        orders, invs = impl(n)
+        assert np.array_equal(np.asarray(orders, dtype=np.int32), g[f"vmamba_{n}.orders"])
+        assert np.array_equal(np.asarray(invs, dtype=np.int32), g[f"vmamba_{n}.inverses"])
+    if n % 2 == 0:                               # the four atrous scans partition the tokens
+        tok = efficient_scan_tokens(n)
+        assert tok.shape == (4, n * n // 4) and sorted(tok.reshape(-1).tolist()) == list(range(n * n))
+    else:
+        with pytest.raises(ValueError):
+            efficient_scan_tokens(n)
+
+
+def _g9(bt):
+    g = load("g9_baseline_blocks.npz")
+    pre = bt + ".sd."
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    inp = {k: torch.from_numpy(g[f"{bt}.{k}"]) for k in ("x", "t", "y", "y2", "w")}
+    return g, sd, inp, int(g[f"{bt}.depth"])
+
+
+@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
+def test_oracle_baseline_blocks_match_reference_output(bt):
+    """the oracle's restatement of the four baseline blocks against the output of the reference's own classes
+    (incl. the ViM branch's feature-axis flip)"""
+    from oracle.model_ref import diffma_forward_ref
+
+    g, sd, inp, depth = _g9(bt)
+    out, blocks = diffma_forward_ref(sd, inp["x"], inp["t"], inp["y"], inp["y2"], inp["w"], patch_size=2, depth=depth,
+                                     dtype=torch.float64, return_blocks=True, block_type=bt)
+    np.testing.assert_allclose(out.numpy(), g[f"{bt}.out"], rtol=1e-4, atol=2e-6)
+    for k in range(depth):
+        np.testing.assert_allclose(blocks[k].numpy(), g[f"{bt}.act.block{k}"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
+def test_product_baseline_models_have_reference_state_dict_layout(bt):
+    from diffma_amd.model import DiffMa
+
+    g, sd, _, depth = _g9(bt)
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
+    own = net.state_dict()
+    assert list(own.keys()) == list(sd.keys())
+    assert all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
+    net.load_state_dict(sd)
+    with pytest.raises(NotImplementedError):
+        DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, block_type="DiT")

@@ -383,3 +383,83 @@ def test_graphed_train_step(gpu):
         torch.testing.assert_close(e_new, 0.9 * e_old + 0.1 * p.detach(), rtol=1e-5, atol=1e-6)
     _, _, _, losses2 = run(12)
     assert losses == losses2
+
+
+# ---- baseline scan orders on the same kernels (tests/golden/g9_baseline_blocks.npz) ------------------------
+def _g9(gpu, bt):
+    from diffma_amd.model import DiffMa
+
+    g = np.load(os.path.join(G, "g9_baseline_blocks.npz"))
+    pre = bt + ".sd."
+    sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
+    depth = int(g[f"{bt}.depth"])
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
+    net.load_state_dict(sd)
+    net = net.to(gpu).eval()
+    inp = {k: torch.from_numpy(g[f"{bt}.{k}"]).to(gpu) for k in ("x", "t", "y", "y2", "w")}
+    return g, sd, net, inp, depth
+
+
+@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
+def test_baseline_blocks_forward_match_reference(gpu, bt):
+    """ZigMa / ViM / VMamba / EfficientVMamba denoisers on the HIP operator against the output of the reference's own
+    classes (operator = fp64 oracle stub): fp32 rel-L2 <= 1e-3 per block and at the output, bf16 autocast <= 2e-2."""
+    g, sd, net, inp, depth = _g9(gpu, bt)
+    acts = {}
+    hooks = [b.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().cpu())) for k, b in enumerate(net.blocks)]
+    with torch.no_grad():
+        out = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).cpu()
+    for h in hooks:
+        h.remove()
+    ref = torch.from_numpy(g[f"{bt}.out"])
+    for k in range(depth):
+        assert rel_l2(acts[k], torch.from_numpy(g[f"{bt}.act.block{k}"])) <= 1e-3, (bt, k)
+    assert rel_l2(out, ref) <= 1e-3, rel_l2(out, ref)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).float().cpu()
+    assert rel_l2(out16, ref) <= 2e-2
+
+
+@pytest.mark.parametrize("scan_type", ["zigma", "vim", "vim-token", "vmamba", "eff"])
+def test_baseline_mixer_forward_backward_match_oracle_autograd(gpu, scan_type):
+    """Mamba.forward(x, scan_type) and its gradients (inputs and all parameters) against fp64 autograd through the oracle."""
+    from diffma_amd.mamba import Mamba
+    from diffma_amd.tools import vmamba_, zig
+    from oracle.mamba_ref import mamba_baseline_forward_ref
+
+    torch.manual_seed(11)
+    n, dm, Bsz = 6, 64, 3
+    L = n * n
+    st = scan_type.split("-")[0]
+    lists = zig(n, 3) if st == "zigma" else (vmamba_(n) if st == "vmamba" else None)
+    kw = dict(token_list=lists[0], origina_list=lists[1]) if lists else {}
+    mix = Mamba(d_model=dm, d_state=16, d_conv=4, expand=2, **kw)
+    with torch.no_grad():
+        mix.A_log.add_(torch.randn_like(mix.A_log) * 0.1)
+        mix.D.add_(torch.randn_like(mix.D) * 0.1)
+    if scan_type == "vim-token":
+        mix.vim_flip = "token"
+    mix = mix.to(gpu)
+    x = torch.randn(Bsz, L, dm)
+    gout = torch.randn(Bsz, L, dm)
+    xg = x.to(gpu).requires_grad_(True)
+    out = mix(xg, st)
+    out.backward(gout.to(gpu))
+
+    params = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mix.named_parameters()}
+    xr = x.double().requires_grad_(True)
+    if scan_type == "vim-token":                 # the intended ViM: flip the second output back along the token axis
+        from oracle.mamba_ref import mamba_inner_ref
+        xz = torch.einsum("ed,bld->bel", params["in_proj.weight"], xr)
+        A = -torch.exp(params["A_log"])
+        inner = lambda t: mamba_inner_ref(t, params["conv1d.weight"], params["conv1d.bias"], params["x_proj.weight"],
+                                          params["dt_proj.weight"], params["out_proj.weight"], None, A, None, None, params["D"],
+                                          delta_bias=params["dt_proj.bias"], delta_softplus=True, dtype=torch.float64)
+        ref = (inner(xz) + torch.flip(inner(torch.flip(xz, [2])), [1])) / 2
+    else:
+        ref = mamba_baseline_forward_ref(xr, params, st, lists, dtype=torch.float64)
+    ref.backward(gout.double())
+    assert rel_l2(out.detach().cpu(), ref.detach()) <= 1e-4
+    assert rel_l2(xg.grad.cpu(), xr.grad) <= 1e-3
+    for k, v in mix.named_parameters():
+        assert rel_l2(v.grad.cpu(), params[k].grad) <= 2e-3, k

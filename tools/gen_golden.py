@@ -82,6 +82,57 @@ def main():
     import diffusion.gaussian_diffusion as ref_gd
     import model as ref_model                      # /root/reference/model.py
 
+    # ---- G9 baseline scan orders and blocks: ZigMa / ViM / VMamba / EfficientVMamba ----------------------
+    def g9():
+        g = {}
+        for n in (4, 7, 14):
+            for i in range(9):
+                a, b = ref_tools.zig(n, i)
+                g[f"zig_{n}_{i}.order"] = np.asarray(a, dtype=np.int32)
+                g[f"zig_{n}_{i}.inverse"] = np.asarray(b, dtype=np.int32)
+            a, b = ref_tools.vmamba_(n)
+            g[f"vmamba_{n}.orders"] = np.asarray(a, dtype=np.int32)
+            g[f"vmamba_{n}.inverses"] = np.asarray(b, dtype=np.int32)
+        # tiny models through the reference classes (operator = oracle stub), one per baseline block type; depth 5 for "zig"
+        # (variants 8, 1, 2, 3, 4; all nine tables are pinned above)
+        for bt, depth in (("zig", 5), ("vim", 4), ("vmamba", 4), ("efficientVMamba", 4)):
+            torch.manual_seed(3000 + depth)
+            net = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
+            gen = torch.Generator().manual_seed(len(bt))
+            with torch.no_grad():
+                for name, p in net.named_parameters():
+                    if p.requires_grad and float(p.abs().max()) == 0.0:
+                        p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+                    if name.endswith("dt_proj.bias"):
+                        dt = torch.exp(torch.rand(p.shape, generator=gen) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+                        p.copy_(dt + torch.log(-torch.expm1(-dt)))
+                    if name.endswith("A_log") or name.endswith(".D"):
+                        p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+            net.eval()
+            N = 2
+            x = torch.randn(N, 4, 8, 8, generator=gen)
+            t = torch.tensor([11, 640])
+            y = torch.randn(N, 64, generator=gen)
+            y2 = torch.randn(N, 16, 64, generator=gen)
+            w = torch.sigmoid(torch.randn(N, 16, 1, generator=gen))
+            acts = {}
+            hooks = [blk.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().numpy())) for k, blk in enumerate(net.blocks)]
+            with torch.no_grad():
+                out = net(x, t, y=y, y2=y2, w=w)
+            for h in hooks:
+                h.remove()
+            g.update({f"{bt}.sd.{k}": v.numpy() for k, v in net.state_dict().items()})
+            g.update({f"{bt}.x": x.numpy(), f"{bt}.t": t.numpy(), f"{bt}.y": y.numpy(), f"{bt}.y2": y2.numpy(), f"{bt}.w": w.numpy(),
+                      f"{bt}.out": out.numpy(), f"{bt}.depth": np.asarray(depth)})
+            g.update({f"{bt}.act.block{k}": v for k, v in acts.items()})
+            print("G9", bt, "params", sum(p.numel() for p in net.parameters()), "out abs mean", float(out.abs().mean()))
+        np.savez_compressed(os.path.join(OUT, "g9_baseline_blocks.npz"), **g)
+
+    if "--only-g9" in sys.argv:
+        g9()
+        return
+    g9()
+
     # ---- G1 spiral -------------------------------------------------------------------------------------
     g1 = {}
     for n in (4, 7, 14):
