@@ -1,4 +1,5 @@
-"""Mamba-2 (SSD) mixer of DiffMa, 'spiral' scan (reference block/mamba2.py:234-457), selected by --use-mamba2.
+"""Mamba-2 (SSD) mixer of DiffMa, 'spiral' scan (reference block/mamba2.py:234-457), selected by --use-mamba2; the baseline
+orders 'zigma' / 'vim' / 'vmamba' (block/mamba2.py:459-615) run on the same operator with 1 / 2 / 4 row-index tables.
 
 State-dict keys match the reference class: in_proj.weight (2*Din + 2*G*N + H, d_model) in the order
 [z | x | B | C | dt], conv1d.weight (Din + 2*G*N, 1, d_conv), conv1d.bias, dt_bias (H), A_log (H), D (H),
@@ -80,24 +81,51 @@ class Mamba2(nn.Module):
 
         self.token_list, self.token_list_reversal = list(token_list), list(token_list_reversal)
         self.origina_list, self.origina_list_reversal = list(origina_list), list(origina_list_reversal)
-        L = len(self.token_list)
+        # token_list is one permutation (spiral, zigma) or a list of four (vmamba, reference model.py:182-186)
+        nested = bool(self.token_list) and isinstance(self.token_list[0], (list, tuple))
+        L = 0 if nested or not self.token_list_reversal else len(self.token_list)
         idx = torch.tensor([list(range(L)), self.token_list, self.token_list_reversal], dtype=torch.int32) if L else torch.zeros((3, 0), dtype=torch.int32)
         self.register_buffer("scan_index", idx, persistent=False)
         self.register_buffer("scan_index_inv", torch.argsort(idx.long(), dim=1).to(torch.int32), persistent=False)
+        self._tables = {}                  # (scan_type, L, device) -> (gather table, inverse) of the baseline scan orders
+
+    def _baseline_tables(self, scan_type, L, device):
+        """ZigMa: the block's one permutation; ViM: identity + time reversal (flipped back along the token axis here, unlike
+        the Mamba-1 twin); VMamba: four permutations (reference block/mamba2.py:459-615).  'eff' raises in the reference
+         and here."""
+        key = (scan_type, L, str(device))
+        tab = self._tables.get(key)
+        if tab is None:
+            if scan_type == "zigma":
+                rows = [self.token_list]
+            elif scan_type == "vim":
+                rows = [list(range(L)), list(range(L - 1, -1, -1))]
+            elif scan_type == "vmamba":
+                rows = self.token_list
+            else:
+                raise NotImplementedError(f"scan_type={scan_type!r} (the reference's Mamba-2 EfficientVMamba branch raises TypeError)")
+            idx = torch.tensor(rows, dtype=torch.int32, device=device)
+            if idx.shape[1] != L:
+                raise ValueError(f"sequence length {L} != scan table length {idx.shape[1]}")
+            tab = (idx, torch.argsort(idx.long(), dim=1).to(torch.int32))
+            self._tables[key] = tab
+        return tab
 
     def forward(self, u, scan_type="spiral", seqlen=None, seq_idx=None, inference_params=None):
         """u: (B, L, d_model) -> (B, L, d_model)."""
-        if scan_type != "spiral":
-            raise NotImplementedError(f"scan_type={scan_type!r}: only the DiffMa 'spiral' path is built")
         if seqlen is not None or seq_idx is not None or inference_params is not None:
             raise NotImplementedError("packed sequences / decode are never used by DiffMa")
         if self.dt_limit != (0.0, float("inf")):
             raise NotImplementedError("dt_limit")
         Bsz, L, _ = u.shape
         Din, N, H, P = self.d_inner, self.d_state, self.nheads, self.headdim
-        ndir = self.scan_index.shape[0]
+        index, index_inv = (self.scan_index, self.scan_index_inv) if scan_type == "spiral" else self._baseline_tables(scan_type, L, u.device)
         zxbcdt = linear_splitk(u, self.in_proj.weight, self.in_proj.bias)             # [B, L, 2*Din + 2N + H], token-major
         A = -torch.exp(self.A_log.float())                                        # [H]
         y = spiral_ssd(zxbcdt, self.conv1d.weight, self.conv1d.bias, self.dt_bias, A, self.D, self.norm.weight, self.norm.eps,
-                       self.scan_index, self.scan_index_inv, Din, N)                 # [B, L, Din]: gated, normalised, merged
+                       index, index_inv, Din, N)                                     # [B, L, Din]: gated, normalised, merged
+        if scan_type == "vim":                                                    # (out1 + out2) / 2, block/mamba2.py:523
+            if self.out_proj.bias is not None:
+                raise NotImplementedError("out_proj bias with averaged directions")
+            y = y * 0.5
         return linear_splitk(y.to(zxbcdt.dtype), self.out_proj.weight, self.out_proj.bias)

@@ -82,12 +82,15 @@ class _BaselineMambaBlock(nn.Module):
 
     def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2=False, token_list=(), origina_list=()):
         super().__init__()
-        if use_mamba2:
-            raise NotImplementedError("the baseline blocks are built on the Mamba-1 mixer only (SURVEY.md A.4-7: the reference's "
-                                      "Mamba-2 twins are partly broken)")
+        if use_mamba2 and self.scan_type == "eff":
+            raise NotImplementedError("EfficientVMamba on the Mamba-2 mixer raises TypeError in the reference too (SURVEY.md A.4-7)")
         self.D_dim, self.E_dim, self.dt_rank, self.dim_inner, self.d_state = D_dim, E_dim, dt_rank, dim_inner, d_state
         self.token_list, self.origina_list = token_list, origina_list
-        mixer = lambda: Mamba(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, token_list=token_list, origina_list=origina_list)
+        if use_mamba2:
+            from .mamba2 import Mamba2 as mixer_cls
+        else:
+            mixer_cls = Mamba
+        mixer = lambda: mixer_cls(d_model=D_dim, d_state=d_state, d_conv=4, expand=2, token_list=token_list, origina_list=origina_list)
         if self.mixer_first:                   # registration order = state-dict key order of the reference class
             self.mamba = mixer()
         self.norm1 = nn.LayerNorm(D_dim)

@@ -85,3 +85,28 @@ def mamba2_spiral_forward_ref(u, params, lists, headdim=64, eps=1e-5, dtype=torc
             outproj_bias=None, headdim=headdim, ngroups=1, norm_before_gate=False, dtype=dtype))
     out = outs[0] + outs[1][:, orig, :] + outs[2][:, orig_rev, :]               # CrossMerge
     return out.to(out_dtype)
+
+
+def mamba2_baseline_forward_ref(u, params, scan_type, lists=None, headdim=64, eps=1e-5, dtype=torch.float64):
+    """Mamba2.forward(u, scan_type) for 'zigma' | 'vim' | 'vmamba' (block/mamba2.py:459-615): the token axis (dim 1 of the
+    (B, L, d_in_proj) in_proj output) is permuted per direction, one combined operator call per direction, outputs scattered
+    back (and averaged for ViM, whose second output IS flipped along the token axis here, block/mamba2.py:502,522)."""
+    out_dtype = u.dtype
+    zx = u.to(dtype) @ params["in_proj.weight"].to(dtype).t()
+    A = -torch.exp(params["A_log"].to(dtype))
+    op = lambda zk: mamba_split_conv1d_scan_combined_ref(
+        zk, params["conv1d.weight"], params["conv1d.bias"], params["dt_bias"], A, params["D"], chunk_size=256, activation="silu",
+        rmsnorm_weight=params["norm.weight"], rmsnorm_eps=eps, outproj_weight=params["out_proj.weight"], outproj_bias=None,
+        headdim=headdim, ngroups=1, norm_before_gate=False, dtype=dtype)
+    lt = lambda v: torch.as_tensor(v, dtype=torch.long)
+    if scan_type == "zigma":
+        order, inv = lists
+        out = op(zx[:, lt(order), :])[:, lt(inv), :]
+    elif scan_type == "vim":
+        out = (op(zx) + torch.flip(op(torch.flip(zx, [1])), [1])) / 2
+    elif scan_type == "vmamba":
+        orders, invs = lists
+        out = sum(op(zx[:, lt(orders[k]), :])[:, lt(invs[k]), :] for k in range(4))
+    else:
+        raise ValueError(scan_type)
+    return out.to(out_dtype)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from .mamba2_ref import mamba2_spiral_forward_ref
+from .mamba2_ref import mamba2_baseline_forward_ref, mamba2_spiral_forward_ref
 from .mamba_ref import mamba_baseline_forward_ref, mamba_spiral_forward_ref, vmamba_lists_ref, zig_lists_ref
 
 
@@ -91,7 +91,10 @@ def diffma_forward_ref(sd, x, t, y, y2, w, *, patch_size, depth, dtype=torch.flo
         if block_type != "spiral":                       # one mixer, no soft mask, no fusion
             scan_type = {"zig": "zigma", "vim": "vim", "vmamba": "vmamba", "efficientVMamba": "eff"}[block_type]
             bl = zig_lists_ref(n_side, i) if block_type == "zig" else (vmamba_lists_ref(n_side) if block_type == "vmamba" else None)
-            h = inp + gate[:, None] * mamba_baseline_forward_ref(xs, sub("mamba"), scan_type, bl, dtype=dtype)
+            if use_mamba2:
+                h = inp + gate[:, None] * mamba2_baseline_forward_ref(xs, sub("mamba"), scan_type, bl, headdim=headdim, dtype=dtype)
+            else:
+                h = inp + gate[:, None] * mamba_baseline_forward_ref(xs, sub("mamba"), scan_type, bl, dtype=dtype)
             outs.append(h)
             continue
         ws = xs * w

@@ -305,37 +305,42 @@ def test_baseline_scan_orders_match_reference(n):
             efficient_scan_tokens(n)
 
 
-def _g9(bt):
+G9_CASES = ["zig", "vim", "vmamba", "efficientVMamba", "m2.zig", "m2.vim", "m2.vmamba"]      # "m2." = the Mamba-2 twins
+
+
+def _g9(tag):
     g = load("g9_baseline_blocks.npz")
-    pre = bt + ".sd."
+    pre = tag + ".sd."
     sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
-    inp = {k: torch.from_numpy(g[f"{bt}.{k}"]) for k in ("x", "t", "y", "y2", "w")}
-    return g, sd, inp, int(g[f"{bt}.depth"])
+    inp = {k: torch.from_numpy(g[f"{tag}.{k}"]) for k in ("x", "t", "y", "y2", "w")}
+    return g, sd, inp, int(g[f"{tag}.depth"]), tag.split(".")[-1], tag.startswith("m2.")
 
 
-@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
-def test_oracle_baseline_blocks_match_reference_output(bt):
-    """the oracle's restatement of the four baseline blocks against the output of the reference's own classes
-    (incl. the ViM branch's feature-axis flip)"""
+@pytest.mark.parametrize("tag", G9_CASES)
+def test_oracle_baseline_blocks_match_reference_output(tag):
+    """the oracle's restatement of the baseline blocks against the output of the reference's own classes
+    (incl. the Mamba-1 ViM branch's feature-axis flip)"""
     from oracle.model_ref import diffma_forward_ref
 
-    g, sd, inp, depth = _g9(bt)
+    g, sd, inp, depth, bt, m2 = _g9(tag)
     out, blocks = diffma_forward_ref(sd, inp["x"], inp["t"], inp["y"], inp["y2"], inp["w"], patch_size=2, depth=depth,
-                                     dtype=torch.float64, return_blocks=True, block_type=bt)
-    np.testing.assert_allclose(out.numpy(), g[f"{bt}.out"], rtol=1e-4, atol=2e-6)
+                                     dtype=torch.float64, return_blocks=True, block_type=bt, use_mamba2=m2)
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}.out"], rtol=1e-4, atol=2e-6)
     for k in range(depth):
-        np.testing.assert_allclose(blocks[k].numpy(), g[f"{bt}.act.block{k}"], rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(blocks[k].numpy(), g[f"{tag}.act.block{k}"], rtol=1e-4, atol=2e-5)
 
 
-@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
-def test_product_baseline_models_have_reference_state_dict_layout(bt):
+@pytest.mark.parametrize("tag", G9_CASES)
+def test_product_baseline_models_have_reference_state_dict_layout(tag):
     from diffma_amd.model import DiffMa
 
-    g, sd, _, depth = _g9(bt)
-    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
+    g, sd, _, depth, bt, m2 = _g9(tag)
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt, use_mamba2=m2)
     own = net.state_dict()
     assert list(own.keys()) == list(sd.keys())
     assert all(tuple(own[k].shape) == tuple(sd[k].shape) for k in sd)
     net.load_state_dict(sd)
     with pytest.raises(NotImplementedError):
         DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, block_type="DiT")
+    with pytest.raises(NotImplementedError):      # raises TypeError in the reference (SURVEY.md A.4-7)
+        DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, block_type="efficientVMamba", use_mamba2=True)

@@ -386,21 +386,22 @@ def test_graphed_train_step(gpu):
 
 
 # ---- baseline scan orders on the same kernels (tests/golden/g9_baseline_blocks.npz) ------------------------
-def _g9(gpu, bt):
+def _g9(gpu, tag):
     from diffma_amd.model import DiffMa
 
     g = np.load(os.path.join(G, "g9_baseline_blocks.npz"))
-    pre = bt + ".sd."
+    pre = tag + ".sd."
     sd = {k[len(pre):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(pre)}
-    depth = int(g[f"{bt}.depth"])
-    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
+    depth = int(g[f"{tag}.depth"])
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=tag.split(".")[-1],
+                 use_mamba2=tag.startswith("m2."))
     net.load_state_dict(sd)
     net = net.to(gpu).eval()
-    inp = {k: torch.from_numpy(g[f"{bt}.{k}"]).to(gpu) for k in ("x", "t", "y", "y2", "w")}
+    inp = {k: torch.from_numpy(g[f"{tag}.{k}"]).to(gpu) for k in ("x", "t", "y", "y2", "w")}
     return g, sd, net, inp, depth
 
 
-@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba"])
+@pytest.mark.parametrize("bt", ["zig", "vim", "vmamba", "efficientVMamba", "m2.zig", "m2.vim", "m2.vmamba"])
 def test_baseline_blocks_forward_match_reference(gpu, bt):
     """ZigMa / ViM / VMamba / EfficientVMamba denoisers on the HIP operator against the output of the reference's own
     classes (operator = fp64 oracle stub): fp32 rel-L2 <= 1e-3 per block and at the output, bf16 autocast <= 2e-2."""
@@ -458,6 +459,37 @@ def test_baseline_mixer_forward_backward_match_oracle_autograd(gpu, scan_type):
         ref = (inner(xz) + torch.flip(inner(torch.flip(xz, [2])), [1])) / 2
     else:
         ref = mamba_baseline_forward_ref(xr, params, st, lists, dtype=torch.float64)
+    ref.backward(gout.double())
+    assert rel_l2(out.detach().cpu(), ref.detach()) <= 1e-4
+    assert rel_l2(xg.grad.cpu(), xr.grad) <= 1e-3
+    for k, v in mix.named_parameters():
+        assert rel_l2(v.grad.cpu(), params[k].grad) <= 2e-3, k
+
+
+@pytest.mark.parametrize("scan_type", ["zigma", "vim", "vmamba"])
+def test_baseline_mamba2_mixer_forward_backward_match_oracle_autograd(gpu, scan_type):
+    """Mamba2.forward(x, scan_type) and its gradients against fp64 autograd through the oracle."""
+    from diffma_amd.mamba2 import Mamba2
+    from diffma_amd.tools import vmamba_, zig
+    from oracle.mamba2_ref import mamba2_baseline_forward_ref
+
+    torch.manual_seed(12)
+    n, dm, Bsz = 6, 64, 3
+    L = n * n
+    lists = zig(n, 6) if scan_type == "zigma" else (vmamba_(n) if scan_type == "vmamba" else None)
+    kw = dict(token_list=lists[0], origina_list=lists[1]) if lists else {}
+    mix = Mamba2(d_model=dm, d_state=16, d_conv=4, expand=2, **kw)
+    with torch.no_grad():
+        mix.norm.weight.add_(torch.randn_like(mix.norm.weight) * 0.1)
+        mix.D.add_(torch.randn_like(mix.D) * 0.1)
+    mix = mix.to(gpu)
+    x, gout = torch.randn(Bsz, L, dm), torch.randn(Bsz, L, dm)
+    xg = x.to(gpu).requires_grad_(True)
+    out = mix(xg, scan_type)
+    out.backward(gout.to(gpu))
+    params = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mix.named_parameters()}
+    xr = x.double().requires_grad_(True)
+    ref = mamba2_baseline_forward_ref(xr, params, scan_type, lists, headdim=mix.headdim, dtype=torch.float64)
     ref.backward(gout.double())
     assert rel_l2(out.detach().cpu(), ref.detach()) <= 1e-4
     assert rel_l2(xg.grad.cpu(), xr.grad) <= 1e-3

@@ -95,10 +95,14 @@ def main():
             g[f"vmamba_{n}.inverses"] = np.asarray(b, dtype=np.int32)
         # tiny models through the reference classes (operator = oracle stub), one per baseline block type; depth 5 for "zig"
         # (variants 8, 1, 2, 3, 4; all nine tables are pinned above)
-        for bt, depth in (("zig", 5), ("vim", 4), ("vmamba", 4), ("efficientVMamba", 4)):
+        # the "m2." entries are the Mamba-2 twins (use_mamba2=True; the EfficientVMamba twin raises TypeError in the reference)
+        for tag, bt, depth, m2 in (("zig", "zig", 5, False), ("vim", "vim", 4, False), ("vmamba", "vmamba", 4, False),
+                                   ("efficientVMamba", "efficientVMamba", 4, False), ("m2.zig", "zig", 2, True),
+                                   ("m2.vim", "vim", 2, True), ("m2.vmamba", "vmamba", 2, True)):
             torch.manual_seed(3000 + depth)
-            net = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt)
-            gen = torch.Generator().manual_seed(len(bt))
+            net = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=depth, d_state=16, block_type=bt,
+                                   use_mamba2=m2)
+            gen = torch.Generator().manual_seed(len(tag))
             with torch.no_grad():
                 for name, p in net.named_parameters():
                     if p.requires_grad and float(p.abs().max()) == 0.0:
@@ -106,9 +110,10 @@ def main():
                     if name.endswith("dt_proj.bias"):
                         dt = torch.exp(torch.rand(p.shape, generator=gen) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
                         p.copy_(dt + torch.log(-torch.expm1(-dt)))
-                    if name.endswith("A_log") or name.endswith(".D"):
+                    if name.endswith("A_log") or name.endswith(".D") or name.endswith("norm.weight"):
                         p.add_(torch.randn(p.shape, generator=gen) * 0.1)
             net.eval()
+            bt = tag
             N = 2
             x = torch.randn(N, 4, 8, 8, generator=gen)
             t = torch.tensor([11, 640])
