@@ -361,7 +361,8 @@ static int ln_by_mod(const dm_ln_mod_args& a, hipStream_t st, bool bwd) {
     switch (a.mod_dtype) {
         case DM_F32: return ln_launch<TX, TY, float>(a, st, bwd);
         case DM_BF16: return ln_launch<TX, TY, bf16_t>(a, st, bwd);
-        default: set_error("dm_ln_mod: mod_dtype must be fp32 or bf16"); return DM_ERR_DTYPE;
+        case DM_F16: return ln_launch<TX, TY, f16_t>(a, st, bwd);
+        default: set_error("dm_ln_mod: mod_dtype must be fp32, bf16 or fp16"); return DM_ERR_DTYPE;
     }
 }
 
@@ -379,6 +380,8 @@ static int ln_entry(const dm_ln_mod_args* args, void* stream, bool bwd) {
     if (a.x_dtype == DM_F32 && a.y_dtype == DM_F32) rc = ln_by_mod<float, float>(a, st, bwd);
     else if (a.x_dtype == DM_F32 && a.y_dtype == DM_BF16) rc = ln_by_mod<float, bf16_t>(a, st, bwd);
     else if (a.x_dtype == DM_BF16 && a.y_dtype == DM_BF16) rc = ln_by_mod<bf16_t, bf16_t>(a, st, bwd);
+    else if (a.x_dtype == DM_F32 && a.y_dtype == DM_F16) rc = ln_by_mod<float, f16_t>(a, st, bwd);      // fp16 autocast (the reference's --autocast)
+    else if (a.x_dtype == DM_F16 && a.y_dtype == DM_F16) rc = ln_by_mod<f16_t, f16_t>(a, st, bwd);
     else { set_error("%s: unsupported (x_dtype, y_dtype) = (%d, %d)", who, a.x_dtype, a.y_dtype); return DM_ERR_DTYPE; }
     if (rc != DM_OK) return rc;
     hipError_t e = hipGetLastError();
@@ -417,6 +420,9 @@ static int blend_entry(const dm_blend_args* args, void* stream, bool bwd) {
         case 11: rc = blend_launch<float, bf16_t, bf16_t>(a, st, bwd); break;
         case 10: rc = blend_launch<float, bf16_t, float>(a, st, bwd); break;
         case 111: rc = blend_launch<bf16_t, bf16_t, bf16_t>(a, st, bwd); break;
+        case 22: rc = blend_launch<float, f16_t, f16_t>(a, st, bwd); break;
+        case 20: rc = blend_launch<float, f16_t, float>(a, st, bwd); break;
+        case 222: rc = blend_launch<f16_t, f16_t, f16_t>(a, st, bwd); break;
         default: set_error("%s: unsupported dtype triple (%d,%d,%d)", who, a.x_dtype, a.s_dtype, a.g_dtype); return DM_ERR_DTYPE;
     }
     if (rc != DM_OK) return rc;

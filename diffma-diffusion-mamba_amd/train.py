@@ -6,7 +6,8 @@
 Same YAML keys, same step (t ~ U{0..T-1}, training_losses, AdamW lr 1e-4 wd 0, EMA 0.999), same checkpoint
 dict {"model","ema","opt","args"} at results_dir/<idx>-<model>/checkpoints/<step:07d>.pt, same log line.
 Differences, all deliberate (SURVEY.md A.4-5,10):
-  * --autocast means bf16 (no GradScaler needed); the reference's fp16+GradScaler is an NVIDIA habit.
+  * --autocast means bf16 (no GradScaler needed) by default; `--amp-dtype fp16` gives the reference's own mode, fp16
+    autocast with a GradScaler (train.py:95,247-263), on the same kernels (fp16 I/O, fp32 scan state).
   * a non-finite loss is detected COLLECTIVELY (all-reduce of a flag) and the step is skipped on every rank;
     the reference `continue`s on one rank only, which dead-locks DDP.
   * frozen encoders (SD-VAE, BiomedCLIP, CT_Encoder) need network weights: with --synthetic (the only mode
@@ -168,7 +169,10 @@ def main(args):
     ema.eval()
     log_steps, running_loss, start_time = 0, 0.0, time()
     max_steps = args.get("max_steps", None)
-    amp = torch.bfloat16 if args.autocast else None
+    amp = (torch.float16 if args.get("amp_dtype", "bf16") == "fp16" else torch.bfloat16) if args.autocast else None
+    scaler = torch.amp.GradScaler(device.type, enabled=amp == torch.float16)     # no-op unless fp16 (reference train.py:95)
+    if amp == torch.float16 and use_graph:
+        raise NotImplementedError("--graph-train with fp16: the GradScaler's skip decision is a host branch; use bf16")
     logger.info(f"Training for {args.epochs} epochs...")
     for epoch in range(args.epochs):
         logger.info(f"Beginning epoch {epoch}...")
@@ -191,13 +195,14 @@ def main(args):
                     loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
                 bad = (~torch.isfinite(loss.detach())).float()
                 dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # every rank takes the same decision
-                loss.backward()                              # always run backward: keeps DDP's bucket all-reduces matched
+                scaler.scale(loss).backward()                # always run backward: keeps DDP's bucket all-reduces matched
                 if bad.item() > 0:
                     logger.info("nan......      ignore losses......")
                     opt.zero_grad(set_to_none=True)
                     continue
                 if train_steps % args.accumulation_steps == 0:
-                    opt.step()
+                    scaler.step(opt)                         # fp16: unscales, skips the update on inf/nan gradients
+                    scaler.update()
                     update_ema(ema, model)
                     opt.zero_grad(set_to_none=True)
                 running_loss += loss.item()
@@ -231,7 +236,8 @@ def main(args):
 def cli(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--wandb", action="store_true", help="accepted for compatibility; wandb is not installed offline")
-    p.add_argument("--autocast", action="store_true", help="bf16 autocast")
+    p.add_argument("--autocast", action="store_true", help="autocast (bf16 unless --amp-dtype fp16)")
+    p.add_argument("--amp-dtype", default="bf16", choices=["bf16", "fp16"], help="fp16 = the reference's mode: fp16 autocast + GradScaler")
     p.add_argument("--use-mamba2", action="store_true")
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning instead of datasets + frozen encoders")
     p.add_argument("--max-steps", type=int, default=None)

@@ -280,7 +280,7 @@ def test_mamba_split_conv1d_scan_combined_signature(gpu):
 
 
 # ---- fused block elementwise kernels (csrc/block_ops.hip) vs the eager ATen formulation ------------------------------------
-@pytest.mark.parametrize("amp", [None, torch.bfloat16])
+@pytest.mark.parametrize("amp", [None, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("hidden,n", [(64, 4), (512, 14)])
 def test_block_fused_elementwise_matches_eager(gpu, amp, hidden, n):
     from diffma_amd.mamba_block import Spiral_MambaBlock
@@ -495,3 +495,30 @@ def test_baseline_mamba2_mixer_forward_backward_match_oracle_autograd(gpu, scan_
     assert rel_l2(xg.grad.cpu(), xr.grad) <= 1e-3
     for k, v in mix.named_parameters():
         assert rel_l2(v.grad.cpu(), params[k].grad) <= 2e-3, k
+
+
+def test_fp16_autocast_with_gradscaler_reference_mode(gpu):
+    """The reference's own mixed-precision mode (train.py:95,247-263: fp16 autocast + GradScaler) on the HIP path: forward
+    within the fp16 end-to-end tolerance of the fp32 golden output, and two scaled optimisation steps that stay finite."""
+    from diffma_amd.diffusion import create_diffusion
+
+    g, sd, net, inp = _g5(gpu)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):
+        out = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).float().cpu()
+    assert rel_l2(out, torch.from_numpy(g["out"])) <= 5e-3
+    net.train()
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0)
+    scaler = torch.amp.GradScaler("cuda")
+    d = create_diffusion("")
+    z, tt = torch.from_numpy(g["loss_z"]).to(gpu), torch.from_numpy(g["loss_t"]).to(gpu)
+    before = net.blocks[0].mamba1.in_proj.weight.detach().clone()
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.float16):
+            loss = d.training_losses(net, z, tt, dict(y=inp["y"], y2=inp["y2"], w=inp["w"]))["loss"].mean()
+        assert torch.isfinite(loss)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad(set_to_none=True)
+    assert scaler.get_scale() > 0
+    assert not torch.equal(before, net.blocks[0].mamba1.in_proj.weight.detach())
