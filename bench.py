@@ -154,6 +154,8 @@ def main():
         if world > 1 or force_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
+            from diffma_amd.mamba_block import ddp_join_streams_hook      # the blocks' two mixer streams both write gradients
+            net.register_comm_hook(None, ddp_join_streams_hook)
         graph_train = args.graph and world == 1 and not force_ddp          # DDP keeps the eager step (bucketed all-reduce)
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True, capturable=graph_train)
         net.train()
@@ -253,17 +255,21 @@ def main():
             kernel_source = "2 eager forward+backward passes after the timed region (the timed steps replay a hipGraph)"
         kernels = {}
         for name, r in ksum.items():
-            gbps = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+            # rate while at least one launch of the kernel is running (= bytes / avg_us when launches never overlap)
+            gbps = r["bytes_per_launch"] * r["launches"] / (r["busy_ms"] * 1e-3) / 1e9
             kernels[name] = dict(launches_per_step=r["launches"] / args.steps, avg_us=round(r["avg_us"], 2),
                                  ms_per_step=round(r["total_ms"] / args.steps, 3), algorithmic_MB_per_launch=round(r["bytes_per_launch"] / 1e6, 3),
-                                 GBps=round(gbps, 1), frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
+                                 concurrent_launches=round(r["total_ms"] / r["busy_ms"], 3), GBps=round(gbps, 1),
+                                 frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
         nsteps_k = args.steps if "timed region" in kernel_source and "after" not in kernel_source else 2
         for v in kernels.values():
             v["launches_per_step"] = v["launches_per_step"] * args.steps / nsteps_k
             v["ms_per_step"] = round(v["ms_per_step"] * args.steps / nsteps_k, 3)
         dom = max(ksum, key=lambda n: ksum[n]["total_ms"])
         r = ksum[dom]
-        achieved = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+        per_launch = r["bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9
+        conc = r["total_ms"] / r["busy_ms"]              # the block's two mixers run on two streams: launches of this kernel overlap
+        achieved = per_launch * conc                     # = all bytes of the kernel / time during which it was running
         # HBM traffic of the same kernel at the same shape from the committed PMC passes (cannot be read live)
         traffic = None
         try:
@@ -288,7 +294,10 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
-                         "timing": kernel_source},
+                         "concurrent_launches": round(conc, 3), "achieved_per_launch": round(per_launch, 1),
+                         "timing": kernel_source + "; achieved = algorithmic bytes per launch / avg_us x concurrent_launches "
+                                   "(launches of the two mixer streams share the GPU; concurrent_launches = sum of launch "
+                                   "durations / union of launch intervals, 1.0 with DIFFMA_OVERLAP_MIXERS=0)"},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":

@@ -32,13 +32,32 @@ class KernelTimer:
         self.records.setdefault(name, []).append((e0, e1, nbytes))
 
     def summary(self):
+        """Per kernel: launches, avg_us / total_ms (per-launch durations, what a kernel trace reports), bytes_per_launch, and
+        busy_ms = the length of the UNION of the launch intervals.  The two mixers of a block run on two streams, so two
+        launches of the same kernel can share the GPU: each then takes about twice as long, while total_ms / busy_ms (the
+        mean number of concurrent launches) tells how many were sharing it."""
         torch.cuda.synchronize()
         out = {}
+        base = None
+        for recs in self.records.values():
+            if recs and base is None:
+                base = recs[0][0]
         for name, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             nb = [n for _, _, n in recs]
+            iv = sorted((base.elapsed_time(a), base.elapsed_time(a) + d) for (a, _, _), d in zip(recs, ms))
+            busy, cur_s, cur_e = 0.0, None, None
+            for s0, e0 in iv:
+                if cur_e is None or s0 > cur_e:
+                    if cur_e is not None:
+                        busy += cur_e - cur_s
+                    cur_s, cur_e = s0, e0
+                else:
+                    cur_e = max(cur_e, e0)
+            if cur_e is not None:
+                busy += cur_e - cur_s
             out[name] = dict(launches=len(recs), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
-                             bytes_per_launch=sum(nb) / len(nb))
+                             bytes_per_launch=sum(nb) / len(nb), busy_ms=busy)
         return out
 
 

@@ -8,6 +8,8 @@ Sub-module names equal the reference's, so state dicts are interchangeable.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -51,6 +53,48 @@ class Spiral_MambaBlock(nn.Module):
             nn.init.constant_(self.attention_network[i].bias, 0)
 
     fused_elementwise = True      # single-pass HIP kernels for the LN/modulate/mask, LN(cat) and blend chains (GPU only)
+    # Run the block's two mixers on two HIP streams.  They are independent, and each alternates between VALU-bound scans and
+    # HBM-bound GEMM / conv / merge kernels, so the two queues fill each other's idle unit (measured: 280 -> 265 ms per
+    # DiffMa-L/2 step at batch 512); autograd replays every backward node on its forward stream, so the backward overlaps the
+    # same way.  Forcing a schedule (scans chained by events, second mixer started at the first one's scan, a high-priority
+    # stream) measured 2-3 % slower than letting the queues run free.  DIFFMA_OVERLAP_MIXERS=0 turns it off.
+    overlap_mixers = os.environ.get("DIFFMA_OVERLAP_MIXERS", "1") != "0"
+    _side_streams = {}
+    _main_streams = {}
+
+    @classmethod
+    def _side_stream(cls, device):
+        st = cls._side_streams.get(device)
+        if st is None:
+            st = cls._side_streams[device] = torch.cuda.Stream(device=device)
+        return st
+
+    @classmethod
+    def join_streams(cls):
+        """Make the current stream wait for everything queued on the two mixer streams (used by the DDP communication hook:
+        a gradient bucket may hold gradients that were copied in on either stream, the collective only orders itself
+        behind the stream that is current when the bucket fills)."""
+        for dev, side in cls._side_streams.items():
+            cur = torch.cuda.current_stream(dev)
+            for st in (side, cls._main_streams.get(dev)):
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
+
+    def _mixers(self, x_ssm, w_ssm):
+        if not (self.overlap_mixers and x_ssm.is_cuda):
+            return self.mamba1(x_ssm, "spiral"), self.mamba2(w_ssm, "spiral")
+        main = torch.cuda.current_stream(x_ssm.device)
+        side = self._side_stream(x_ssm.device)
+        self._main_streams[x_ssm.device] = main
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            w_in = w_ssm
+            w_ssm = self.mamba2(w_in, "spiral")
+        w_in.record_stream(side)                  # allocated on `main`, read on `side`
+        x_ssm = self.mamba1(x_ssm, "spiral")
+        main.wait_stream(side)
+        w_ssm.record_stream(main)                 # allocated on `side`, read on `main`
+        return x_ssm, w_ssm
 
     def forward(self, x, c, w):
         shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
@@ -58,8 +102,7 @@ class Spiral_MambaBlock(nn.Module):
             act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
             block_ops.set_output_dtype(act)
             x_ssm, w_ssm = block_ops.ln_modulate_mask(x, self.norm1, shift, scale, w)
-            x_ssm = self.mamba1(x_ssm, "spiral")
-            w_ssm = self.mamba2(w_ssm, "spiral")
+            x_ssm, w_ssm = self._mixers(x_ssm, w_ssm)
             net = self.attention_network
             # the two Linear layers of the fusion MLP through linear_splitk: their weight gradients reduce over B*L rows
             hcat = block_ops.ln_cat(x_ssm, w_ssm, net[0])
@@ -140,3 +183,12 @@ class EfficientVMamba_MambaBlock(_BaselineMambaBlock):
 
     def __init__(self, D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2=False):
         super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2)
+
+
+def ddp_join_streams_hook(process_group, bucket):
+    """DDP communication hook for models whose blocks run their mixers on two streams: join the streams, then the stock
+    all-reduce (mean over ranks).  Register with `ddp.register_comm_hook(process_group_or_None, ddp_join_streams_hook)`."""
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+    Spiral_MambaBlock.join_streams()
+    return default_hooks.allreduce_hook(process_group, bucket)
