@@ -296,8 +296,8 @@ def main():
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
                          "concurrent_launches": round(conc, 3), "achieved_per_launch": round(per_launch, 1),
                          "timing": kernel_source + "; achieved = algorithmic bytes per launch / avg_us x concurrent_launches "
-                                   "(launches of the two mixer streams share the GPU; concurrent_launches = sum of launch "
-                                   "durations / union of launch intervals, 1.0 with DIFFMA_OVERLAP_MIXERS=0)"},
+                                   "(concurrent_launches = sum of launch durations / union of launch intervals: 1.0 unless the "
+                                   "opt-in two-stream mode DIFFMA_OVERLAP_MIXERS=1 lets launches of the two mixers share the GPU)"},
             "kernels": kernels,
         }
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":

@@ -53,12 +53,15 @@ class Spiral_MambaBlock(nn.Module):
             nn.init.constant_(self.attention_network[i].bias, 0)
 
     fused_elementwise = True      # single-pass HIP kernels for the LN/modulate/mask, LN(cat) and blend chains (GPU only)
-    # Run the block's two mixers on two HIP streams.  They are independent, and each alternates between VALU-bound scans and
-    # HBM-bound GEMM / conv / merge kernels, so the two queues fill each other's idle unit (measured: 280 -> 265 ms per
-    # DiffMa-L/2 step at batch 512); autograd replays every backward node on its forward stream, so the backward overlaps the
-    # same way.  Forcing a schedule (scans chained by events, second mixer started at the first one's scan, a high-priority
-    # stream) measured 2-3 % slower than letting the queues run free.  DIFFMA_OVERLAP_MIXERS=0 turns it off.
-    overlap_mixers = os.environ.get("DIFFMA_OVERLAP_MIXERS", "1") != "0"
+    # OPT-IN (DIFFMA_OVERLAP_MIXERS=1): run the block's two mixers on two HIP streams.  They are independent, and each
+    # alternates between VALU-bound scans and HBM-bound GEMM / conv / merge kernels, so the two queues fill each other's idle
+    # unit (measured: 280 -> 265 ms per DiffMa-L/2 step at batch 512, 22.7 -> 18.5 ms for the graphed batch-8 step); autograd
+    # replays every backward node on its forward stream, so the backward overlaps the same way.  Forcing a schedule (scans
+    # chained by events, second mixer started at the first one's scan, a high-priority stream) measured 2-3 % slower than
+    # letting the queues run free.  NOT the default: the GEMM libraries' persistent stream-K kernels spin-wait for their own
+    # not-yet-resident workgroups, and two of them co-scheduled from two queues can starve each other -- DiffMa-XL/2 with
+    # Mamba-2 mixers hung the GPU that way (the DiffMa-L/2 shapes of the recorded solution table never did in ~20 runs).
+    overlap_mixers = os.environ.get("DIFFMA_OVERLAP_MIXERS", "0") == "1"
     _side_streams = {}
     _main_streams = {}
 

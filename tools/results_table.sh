@@ -8,3 +8,8 @@ run --model DiffMa-XL/2 --use-mamba2 --batch-per-gpu 64 --steps 5 --warmup 2
 run --model DiffMa-XL/2 --batch-per-gpu 64 --steps 5 --warmup 2
 run --mode sample --graph --sampler ddim50 --model DiffMa-XXL/2 --batch-per-gpu 8 --steps 30 --warmup 5
 run --mode sample --graph --sampler ddim50 --model DiffMa-XXL/2 --batch-per-gpu 64 --steps 30 --warmup 5
+run --model DiffMa-L/2 --batch-per-gpu 8 --steps 20
+run --model DiffMa-L/2 --batch-per-gpu 8 --steps 20 --graph
+run --mode sample --graph --model DiffMa-L/2 --batch-per-gpu 1 --steps 50 --warmup 5
+run --mode sample --graph --model DiffMa-L/2 --batch-per-gpu 8 --steps 50 --warmup 5
+run --mode sample --graph --model DiffMa-L/2 --batch-per-gpu 64 --steps 50 --warmup 5
