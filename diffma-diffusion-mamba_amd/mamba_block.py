@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import block_ops
 from .mamba import Mamba
-from .selective_scan_interface import linear_splitk
+from .selective_scan_interface import GemmChain, linear_splitk
 
 
 def modulate(x, shift, scale):
@@ -60,7 +60,9 @@ class Spiral_MambaBlock(nn.Module):
     # chained by events, second mixer started at the first one's scan, a high-priority stream) measured 2-3 % slower than
     # letting the queues run free.  NOT the default: the GEMM libraries' persistent stream-K kernels spin-wait for their own
     # not-yet-resident workgroups, and two of them co-scheduled from two queues can starve each other -- DiffMa-XL/2 with
-    # Mamba-2 mixers hung the GPU that way (the DiffMa-L/2 shapes of the recorded solution table never did in ~20 runs).
+    # Mamba-2 mixers hung the GPU that way, 3 runs of 3 (the DiffMa-L/2 shapes of the recorded solution table never did in ~20
+    # runs).  With every GEMM of the two streams chained behind the previous one (GemmChain, on by default in this mode) the
+    # hang is gone, and so is the gain (281 ms): what overlapped profitably were the small GEMMs with each other.
     overlap_mixers = os.environ.get("DIFFMA_OVERLAP_MIXERS", "0") == "1"
     _side_streams = {}
     _main_streams = {}
@@ -89,6 +91,9 @@ class Spiral_MambaBlock(nn.Module):
         main = torch.cuda.current_stream(x_ssm.device)
         side = self._side_stream(x_ssm.device)
         self._main_streams[x_ssm.device] = main
+        # no two library GEMMs resident together (persistent stream-K kernels); DIFFMA_GEMM_CHAIN=0 drops the guard: that is
+        # where the measured gain comes from, and what can hang
+        GemmChain.enabled = os.environ.get("DIFFMA_GEMM_CHAIN", "1") != "0"
         side.wait_stream(main)
         with torch.cuda.stream(side):
             w_in = w_ssm

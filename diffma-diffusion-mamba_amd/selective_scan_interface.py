@@ -138,7 +138,35 @@ def causal_conv1d_fn(x, weight, bias=None, seq_idx=None, initial_states=None, re
     return _CausalConv1dFn.apply(x, weight, bias, activation is not None)
 
 
+class GemmChain:
+    """Used only by the opt-in two-stream mode of the block (mamba_block.Spiral_MambaBlock._mixers): every GEMM of the two
+    mixer streams is chained behind the previous one with an event, so that no two library GEMMs are ever resident together.
+    hipBLASLt / Tensile's persistent stream-K kernels spin-wait for their own not-yet-scheduled workgroups; two of them
+    co-scheduled from two queues can starve each other (observed as a GPU hang).  GEMM next to scan / conv / merge kernels
+    stays concurrent -- those workgroups always retire."""
+    enabled = False
+    event = None
+    stream = None
+
+    @classmethod
+    def run(cls, fn, *args, **kw):
+        if not cls.enabled or not torch.cuda.is_available():
+            return fn(*args, **kw)
+        cur = torch.cuda.current_stream()
+        if cls.event is not None and cls.stream != cur:
+            cur.wait_event(cls.event)
+        out = fn(*args, **kw)
+        cls.event = torch.cuda.Event()
+        cls.event.record(cur)
+        cls.stream = cur
+        return out
+
+
 def _tn_splitk(a, b):
+    return GemmChain.run(_tn_splitk_impl, a, b)
+
+
+def _tn_splitk_impl(a, b):
     """a^T @ b for tall operands a (M, P), b (M, Q): the reduction runs over M = B*L or ndir*B*L (50 176 /
     150 528 at the bench shape), which hipBLASLt does not split -- a single-pass GEMM is 2-8x off its memory
     time (x_proj: 492 us vs 82 us; in_proj: 194 us vs 128 us even after solution tuning; tools/bench_gemm.py).
@@ -164,7 +192,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         wc = weight if weight.dtype == dt_ else weight.to(dt_)
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return F.linear(xc, wc, None if bias is None else bias.to(dt_))
+        return GemmChain.run(F.linear, xc, wc, None if bias is None else bias.to(dt_))
 
     @staticmethod
     def backward(ctx, dy):
@@ -175,7 +203,7 @@ class _LinearSplitKFn(torch.autograd.Function):
             if dy2.dtype != xc.dtype:
                 dy2 = dy2.to(xc.dtype)
             x2 = xc.reshape(-1, xc.shape[-1])
-            dx = (dy2 @ wc).view(xc.shape).to(x_dt) if ctx.needs_input_grad[0] else None
+            dx = GemmChain.run(torch.mm, dy2, wc).view(xc.shape).to(x_dt) if ctx.needs_input_grad[0] else None
             dw = _tn_splitk(dy2.contiguous(), x2.contiguous()).to(w_dt) if ctx.needs_input_grad[1] else None
             db = dy2.sum(0, dtype=torch.float32).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return dx, dw, db
@@ -213,8 +241,8 @@ class _SpiralSSMFn(torch.autograd.Function):
         need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
         xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
         Wx_c, Wdt_c = Wx.to(dt_), Wdt.to(dt_)                                  # kept for the backward (one cast per step, not two)
-        x_dbl = F.linear(xc.view(-1, Din), Wx_c)                               # [ndir*B*L, R+2N]
-        delta = F.linear(x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
+        x_dbl = GemmChain.run(F.linear, xc.view(-1, Din), Wx_c)                # [ndir*B*L, R+2N]
+        delta = GemmChain.run(F.linear, x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         ckpt = None
@@ -253,11 +281,11 @@ class _SpiralSSMFn(torch.autograd.Function):
             out_row_index=oidx, batch_per_dir=Bsz, dout_per_seq=not ctx.merge,
             dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
-        dx_dbl[:, :R] = ddelta2 @ Wdt_c            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
+        dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
-        dxc = du.view(M, Din).addmm_(dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
+        dxc = GemmChain.run(du.view(M, Din).addmm_, dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                row_index=scan_index, ndir=ndir, silu=True)
         dxz = torch.empty_like(xz)
