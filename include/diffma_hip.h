@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 8
+#define DM_ABI_VERSION 9
 
 typedef enum {
     DM_OK = 0,
