@@ -1,4 +1,4 @@
-run() { python bench.py --cpu-steps 0 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '| ms/step', d['ms_per_step'], '| value', d['value'], '| roof', d['roofline']['kernel'], d['roofline']['frac'])"; }
+run() { timeout -k 5 400 python bench.py --cpu-steps 0 "$@" 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', '| ms/step', d['ms_per_step'], '| value', d['value'], '| roof', d['roofline']['kernel'], d['roofline']['frac'])"; }
 run --mode sample --graph --model DiffMa-B/4 --batch-per-gpu 8 --dtype fp32 --steps 50 --warmup 5
 run --mode sample --graph --model DiffMa-B/4 --batch-per-gpu 64 --dtype fp32 --steps 50 --warmup 5
 run --mode sample --graph --model DiffMa-B/4 --batch-per-gpu 64 --dtype bf16 --steps 50 --warmup 5
