@@ -522,3 +522,34 @@ def test_fp16_autocast_with_gradscaler_reference_mode(gpu):
         opt.zero_grad(set_to_none=True)
     assert scaler.get_scale() > 0
     assert not torch.equal(before, net.blocks[0].mamba1.in_proj.weight.detach())
+
+
+def test_two_stream_mixers_match_single_stream(gpu):
+    """The opt-in two-stream mode of the block (mamba_block.Spiral_MambaBlock.overlap_mixers): same loss and gradients as
+    the single-stream default (the kernels and their order per mixer are identical, only the queues differ)."""
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.mamba_block import Spiral_MambaBlock
+
+    g, sd, net, inp = _g5(gpu)
+    net.train()
+    d = create_diffusion("")
+    z, nz, tt = (torch.from_numpy(g[k]).to(gpu) for k in ("loss_z", "loss_noise", "loss_t"))
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        loss = d.training_losses(net, z, tt, dict(y=inp["y"], y2=inp["y2"], w=inp["w"]), noise=nz)["loss"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    l0, g0 = run()
+    prev = Spiral_MambaBlock.overlap_mixers
+    Spiral_MambaBlock.overlap_mixers = True
+    try:
+        l1, g1 = run()
+    finally:
+        Spiral_MambaBlock.overlap_mixers = prev
+    assert torch.equal(l0, l1)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        torch.testing.assert_close(g1[k], g0[k], rtol=1e-5, atol=1e-7, msg=k)
