@@ -154,8 +154,9 @@ def main():
         if world > 1 or force_ddp:
             from torch.nn.parallel import DistributedDataParallel as DDP
             net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
-            from diffma_amd.mamba_block import ddp_join_streams_hook      # the blocks' two mixer streams both write gradients
-            net.register_comm_hook(None, ddp_join_streams_hook)
+            from diffma_amd.mamba_block import Spiral_MambaBlock, ddp_join_streams_hook
+            if Spiral_MambaBlock.overlap_mixers:                          # opt-in two-stream mode: both streams write gradients
+                net.register_comm_hook(None, ddp_join_streams_hook)
         graph_train = args.graph and world == 1 and not force_ddp          # DDP keeps the eager step (bucketed all-reduce)
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True, capturable=graph_train)
         net.train()

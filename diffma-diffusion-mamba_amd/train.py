@@ -148,8 +148,8 @@ def main(args):
     else:
         ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
                   bucket_cap_mb=64)
-        if device.type == "cuda":                    # the blocks' two mixer streams both write gradients (mamba_block.py)
-            from .mamba_block import ddp_join_streams_hook
+        from .mamba_block import Spiral_MambaBlock, ddp_join_streams_hook
+        if device.type == "cuda" and Spiral_MambaBlock.overlap_mixers:   # opt-in two-stream mode: both streams write gradients
             ddp.register_comm_hook(None, ddp_join_streams_hook)
     diffusion = create_diffusion(timestep_respacing="")
     logger.info(f"DiffMa Parameters: {sum(p.numel() for p in model.parameters()):,}")
