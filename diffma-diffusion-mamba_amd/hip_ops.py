@@ -16,6 +16,21 @@ _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
 
 
+def union_length(intervals):
+    """Total length of the union of (start, end) intervals (overlapping launches of one kernel count once)."""
+    total, cur_s, cur_e = 0.0, None, None
+    for s0, e0 in sorted(intervals):
+        if cur_e is None or s0 > cur_e:
+            if cur_e is not None:
+                total += cur_e - cur_s
+            cur_s, cur_e = s0, e0
+        else:
+            cur_e = max(cur_e, e0)
+    if cur_e is not None:
+        total += cur_e - cur_s
+    return total
+
+
 class KernelTimer:
     """Optional live timing of the C-ABI launches with events recorded on the launch stream (the torch
     current stream).  bench.py installs one around its timed region; no host sync until `summary()`."""
@@ -45,17 +60,7 @@ class KernelTimer:
         for name, recs in self.records.items():
             ms = [a.elapsed_time(b) for a, b, _ in recs]
             nb = [n for _, _, n in recs]
-            iv = sorted((base.elapsed_time(a), base.elapsed_time(a) + d) for (a, _, _), d in zip(recs, ms))
-            busy, cur_s, cur_e = 0.0, None, None
-            for s0, e0 in iv:
-                if cur_e is None or s0 > cur_e:
-                    if cur_e is not None:
-                        busy += cur_e - cur_s
-                    cur_s, cur_e = s0, e0
-                else:
-                    cur_e = max(cur_e, e0)
-            if cur_e is not None:
-                busy += cur_e - cur_s
+            busy = union_length((base.elapsed_time(a), base.elapsed_time(a) + d) for (a, _, _), d in zip(recs, ms))
             out[name] = dict(launches=len(recs), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
                              bytes_per_launch=sum(nb) / len(nb), busy_ms=busy)
         return out

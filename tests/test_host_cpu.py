@@ -148,3 +148,14 @@ def test_checkpoint_resume_and_sampler_load(tmp_path):
     """Checkpoint dict {"model","ema","opt","args"} (reference train.py:291-303): written, resumed from, and its EMA
     loaded the way sample.py does."""
     mp.spawn(_resume_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+
+
+def test_kernel_timer_union_of_launch_intervals():
+    """bench.py's roofline accounting: overlapping launches of one kernel (two-stream mode) count once in the busy time."""
+    from diffma_amd.hip_ops import union_length
+
+    assert union_length([]) == 0.0
+    assert union_length([(0.0, 1.0), (2.0, 3.5)]) == 2.5                       # disjoint: the plain sum
+    assert union_length([(0.0, 2.0), (1.0, 3.0)]) == 3.0                       # two launches sharing the GPU
+    assert union_length([(5.0, 6.0), (0.0, 10.0), (2.0, 3.0)]) == 10.0         # nested, unsorted input
+    assert union_length([(0.0, 1.0), (1.0, 2.0)]) == 2.0                       # back to back
