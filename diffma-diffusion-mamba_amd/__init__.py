@@ -11,3 +11,12 @@ the importable name onto this directory).  Layout:
   diffusion/                  create_diffusion / GaussianDiffusion           (diffusion/*)
 """
 __version__ = "0.1.0"
+
+import os as _os
+
+if _os.environ.get("DIFFMA_OVERLAP_MIXERS") == "1":
+    # The opt-in two-stream mode must never meet a persistent stream-K GEMM (mamba_block.py): ask hipBLASLt's Tensile for its
+    # data-parallel form before the library is initialised.  (Measured: with this setting the configuration that hung 3 of 3
+    # runs completed 9 of 9, at the full two-stream speed.)
+    _os.environ.setdefault("TENSILE_STREAMK_DATA_PARALLEL", "1")
+

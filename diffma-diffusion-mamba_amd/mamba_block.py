@@ -61,8 +61,9 @@ class Spiral_MambaBlock(nn.Module):
     # letting the queues run free.  NOT the default: the GEMM libraries' persistent stream-K kernels spin-wait for their own
     # not-yet-resident workgroups, and two of them co-scheduled from two queues can starve each other -- DiffMa-XL/2 with
     # Mamba-2 mixers hung the GPU that way, 3 runs of 3 (the DiffMa-L/2 shapes of the recorded solution table never did in ~20
-    # runs).  With every GEMM of the two streams chained behind the previous one (GemmChain, on by default in this mode) the
-    # hang is gone, and so is the gain (281 ms): what overlapped profitably were the small GEMMs with each other.
+    # runs).  With every GEMM of the two streams chained behind the previous one (GemmChain) the hang is gone, and so is the
+    # gain (281 ms): what overlapped profitably were the small GEMMs with each other.  TENSILE_STREAMK_DATA_PARALLEL=1 (set by
+    # the package when this mode is requested) removes the spin-waits instead and keeps the gain; 11 clean runs so far.
     overlap_mixers = os.environ.get("DIFFMA_OVERLAP_MIXERS", "0") == "1"
     _side_streams = {}
     _main_streams = {}
@@ -91,9 +92,10 @@ class Spiral_MambaBlock(nn.Module):
         main = torch.cuda.current_stream(x_ssm.device)
         side = self._side_stream(x_ssm.device)
         self._main_streams[x_ssm.device] = main
-        # no two library GEMMs resident together (persistent stream-K kernels); DIFFMA_GEMM_CHAIN=0 drops the guard: that is
-        # where the measured gain comes from, and what can hang
-        GemmChain.enabled = os.environ.get("DIFFMA_GEMM_CHAIN", "1") != "0"
+        # No two library GEMMs resident together while persistent stream-K kernels are possible.  With hipBLASLt's stream-K in
+        # data-parallel form (TENSILE_STREAMK_DATA_PARALLEL=1, set by the package when the mode is requested through the
+        # environment) the guard is off: GEMM next to GEMM is where the gain comes from.
+        GemmChain.enabled = os.environ.get("DIFFMA_GEMM_CHAIN", "0" if os.environ.get("TENSILE_STREAMK_DATA_PARALLEL") == "1" else "1") != "0"
         side.wait_stream(main)
         with torch.cuda.stream(side):
             w_in = w_ssm
