@@ -12,6 +12,8 @@ scaling is weak; `value` = samples*steps per second summed over all ranks ("diff
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline     : the dominant C-ABI kernel of the timed region, timed with events on the launch stream
   kernels      : the same numbers for every C-ABI kernel
+  gemm         : FLOPs and device time of the GEMMs of one step, as a fraction of the dense bf16 MFMA peak
+  selective_scan_fn : the scan kernels on their own at the DiffMa-L/2 operator shape (north-star metric, N = 1 only)
   cpu_baseline : the oracle port of the same training step on the host cores (rank 0, N = 1 only)
 """
 import argparse
@@ -27,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
 def parse():
@@ -39,7 +43,8 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=512)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--mode", default="train", choices=["train", "sample"])
-    ap.add_argument("--cpu-steps", type=int, default=1, help="training steps of the CPU oracle baseline (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="timed training steps of the CPU oracle baseline, median reported (>= 5; 0 = skip)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the scan micro-benchmark and the GEMM accounting")
     ap.add_argument("--global-seed", type=int, default=0)
     ap.add_argument("--gemm-tuning", default="file", choices=["file", "frozen", "off", "tune"],
                     help="hipBLASLt/rocBLAS solution selection (diffma_amd.gemm_tuning): file = recorded table, shapes it does not know "
@@ -75,17 +80,18 @@ def update_ema(ema, model, decay=0.999):
     torch._foreach_add_(ep, mp, alpha=1 - decay)
 
 
-def cpu_baseline(args, tokens):
-    """The oracle ("port") run of the same training step on the host: batch 1, fp32, all cores."""
+def _cpu_train_steps(model_name, timed, threads):
+    """`timed` + 1 training steps (fwd + bwd + AdamW, batch 1, fp32) of the oracle port; the first is an untimed warm-up.
+    Returns the per-step wall times."""
     from diffma_amd.diffusion import create_diffusion
     from diffma_amd.model import DiffMa_models
     from oracle.model_ref import diffma_forward_ref
 
-    threads = min(16, os.cpu_count() or 1)      # the op-by-op oracle does not scale past ~16 threads (tiny ops)
     torch.set_num_threads(threads)
     torch.manual_seed(0)
-    net = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
+    net = DiffMa_models[model_name](input_size=28, dt_rank=16, d_state=16, use_mamba2=False)
     rerandomize_zero_init(net, 1)
+    tokens = net.x_embedder.num_patches
     sd = {k: v.detach().clone().requires_grad_(k != "pos_embed") for k, v in net.state_dict().items()}
     params = [v for k, v in sd.items() if k != "pos_embed"]
     opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0)
@@ -95,17 +101,111 @@ def cpu_baseline(args, tokens):
     depth, patch = net.depth, net.patch_size
     model = lambda x, t, **kw: diffma_forward_ref(sd, x, t, kw["y"], kw["y2"], kw["w"], patch_size=patch, depth=depth, dtype=torch.float32,
                                                   block_type=net.block_type)
-    t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    times = []
+    for _ in range(timed + 1):
+        t0 = time.perf_counter()
         t = torch.randint(0, d.num_timesteps, (1,))
         loss = d.training_losses(model, b["z"], t, dict(y=b["y"], y2=b["y2"], w=b["w"]))["loss"].mean()
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
-    dt = time.perf_counter() - t0
-    return {"value": args.cpu_steps * 1 / dt, "unit": "samples*steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{args.cpu_steps} training steps (fwd+bwd+AdamW) of {args.model} at batch 1, fp32, pure-PyTorch oracle "
-                      f"(sequential scan), {dt:.1f} s"}
+        times.append(time.perf_counter() - t0)
+    return times[1:]
+
+
+def cpu_baseline(args, tokens):
+    """SURVEY.md 8(d) / BASELINE.md section 5: the oracle ("port") of the same training step on the host cores -- batch 1, fp32,
+    torch.set_num_threads(os.cpu_count()), median of >= 5 steps after one warm-up step, for the bench model and for
+    DiffMa-S/7 (BASELINE config 1)."""
+    import statistics
+
+    threads = os.cpu_count() or 1
+    n = max(5, args.cpu_steps)
+    main_t = _cpu_train_steps(args.model, n, threads)
+    s7_t = _cpu_train_steps("DiffMa-S/7", n, threads)
+    med, med7 = statistics.median(main_t), statistics.median(s7_t)
+    return {"value": 1.0 / med, "unit": "samples*steps/s", "cores": threads, "kind": "port",
+            "sample": f"median of {n} training steps (fwd+bwd+AdamW) after 1 warm-up step, {args.model} at batch 1, fp32, pure-PyTorch "
+                      f"oracle (sequential scan), {threads} threads = os.cpu_count(); {sum(main_t):.1f} s of timed CPU work",
+            "step_seconds": [round(x, 3) for x in main_t],
+            "s7": {"model": "DiffMa-S/7", "value": 1.0 / med7, "unit": "samples*steps/s", "step_seconds": [round(x, 4) for x in s7_t]}}
+
+
+def scan_microbench(dev, nseq=768, L=196, Dm=1024, N=16, iters=20):
+    """The north-star metric proper: `selective_scan_fn` on its own -- forward without checkpoints and the
+    training pair (forward with checkpoints + backward) -- at the DiffMa-L/2 operator shape, fp32 and bf16 I/O, timed with
+    events on the launch stream.  GB/s = SURVEY.md 8(d) algorithmic bytes / time."""
+    from diffma_amd import hip_ops
+
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(0)
+    mk = lambda *s: torch.randn(*s, generator=g, device=dev)
+    for name, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        es = 4 if dt == torch.float32 else 2
+        u, delta, z, dout = mk(nseq, L, Dm).to(dt), (mk(nseq, L, Dm) * 0.5).to(dt), mk(nseq, L, Dm).to(dt), mk(nseq, L, Dm).to(dt)
+        A = -(torch.rand(Dm, N, generator=g, device=dev) * 4 + 0.2)
+        Bm, Cm, Dp, bias = mk(nseq, L, N).to(dt), mk(nseq, L, N).to(dt), mk(Dm), mk(Dm) * 0.5
+        y = torch.empty_like(u)
+        ckpt = hip_ops.alloc_scan_ckpt(nseq, L, N, Dm, dt, dev)
+
+        def timeit(fn):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / iters * 1e-3
+
+        t_f = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=y))
+        t_fc = timeit(lambda: hip_ops.scan_fwd(u, delta, A, Bm, Cm, Dp, z, bias, True, out=y, ckpt=ckpt))
+        t_b = timeit(lambda: hip_ops.scan_bwd(u, delta, A, Bm, Cm, Dp, z, bias, dout, ckpt, True))     # incl. the partial-row sums
+        bf = hip_ops.scan_fwd_algorithmic_bytes(nseq, Dm, L, N, es, es)
+        bb = hip_ops.scan_bwd_algorithmic_bytes(nseq, Dm, L, N, es)
+        row = lambda t, nb: {"us": round(t * 1e6, 1), "GBps": round(nb / t / 1e9, 1), "frac": round(nb / t / 1e9 / HBM_PEAK_GBPS, 4),
+                             "frac_of_measured_copy_ceiling": round(nb / t / 1e9 / HBM_COPY_GBPS, 4), "algorithmic_bytes": nb}
+        out[name] = {"fwd": row(t_f, bf), "fwd_with_checkpoints": row(t_fc, bf), "bwd_incl_partial_sums": row(t_b, bb)}
+        del u, delta, z, dout, y, ckpt
+    out["shape"] = {"nseq": nseq, "L": L, "D": Dm, "N": N, "iters": iters}
+    return out
+
+
+def gemm_accounting(step, steps_time_ms):
+    """GEMM FLOPs of one step (torch FlopCounterMode: every aten mm / addmm / bmm / convolution actually executed, forward and
+    backward) and the device time of the GEMM kernels of one step (torch.profiler kernel records whose name is a Tensile /
+    rocBLAS / hipBLASLt GEMM), both taken on extra steps AFTER the timed region."""
+    import re
+
+    from torch.profiler import ProfilerActivity, profile
+    from torch.utils.flop_counter import FlopCounterMode
+
+    with FlopCounterMode(display=False) as fc:
+        step()
+    torch.cuda.synchronize()
+    flops = int(fc.get_total_flops())
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        step()
+        torch.cuda.synchronize()
+    pat = re.compile(r"Cijk_|gemm|Gemm|GEMM|gemv")
+    gemm_us = other_us = 0.0
+    n_gemm = 0
+    for e in prof.key_averages():
+        t = float(getattr(e, "self_device_time_total", 0.0) or 0.0)
+        if t <= 0:
+            continue
+        if pat.search(e.key):
+            gemm_us += t
+            n_gemm += e.count
+        else:
+            other_us += t
+    ms = gemm_us * 1e-3
+    return {"flops_per_step": flops, "ms_per_step": round(ms, 3), "launches_per_step": n_gemm,
+            "TFLOPs": round(flops / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, "peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+            "frac_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if ms > 0 else None,
+            "share_of_step": round(ms / steps_time_ms, 4), "all_kernels_ms_in_profiled_step": round((gemm_us + other_us) * 1e-3, 3),
+            "source": "one step under FlopCounterMode (FLOPs) and one under torch.profiler (GEMM kernel time), both after the timed region"}
 
 
 def main():
@@ -152,11 +252,8 @@ def main():
         ema = copy.deepcopy(model).requires_grad_(False)
         net = model
         if world > 1 or force_ddp:
-            from torch.nn.parallel import DistributedDataParallel as DDP
-            net = DDP(model, device_ids=[local], gradient_as_bucket_view=True, bucket_cap_mb=64, static_graph=True)
-            from diffma_amd.mamba_block import Spiral_MambaBlock, ddp_join_streams_hook
-            if Spiral_MambaBlock.overlap_mixers:                          # opt-in two-stream mode: both streams write gradients
-                net.register_comm_hook(None, ddp_join_streams_hook)
+            from diffma_amd.train import wrap_ddp                        # the SAME wrapper (buckets, static_graph, hooks) as train.py
+            net = wrap_ddp(model, dev, grad_compression=os.environ.get("DIFFMA_GRAD_COMPRESSION", "none"))
         graph_train = args.graph and world == 1 and not force_ddp          # DDP keeps the eager step (bucketed all-reduce)
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True, capturable=graph_train)
         net.train()
@@ -258,10 +355,12 @@ def main():
         for name, r in ksum.items():
             # rate while at least one launch of the kernel is running (= bytes / avg_us when launches never overlap)
             gbps = r["bytes_per_launch"] * r["launches"] / (r["busy_ms"] * 1e-3) / 1e9
+            gbps_d = r["design_bytes_per_launch"] * r["launches"] / (r["busy_ms"] * 1e-3) / 1e9
             kernels[name] = dict(launches_per_step=r["launches"] / args.steps, avg_us=round(r["avg_us"], 2),
                                  ms_per_step=round(r["total_ms"] / args.steps, 3), algorithmic_MB_per_launch=round(r["bytes_per_launch"] / 1e6, 3),
+                                 design_MB_per_launch=round(r["design_bytes_per_launch"] / 1e6, 3),
                                  concurrent_launches=round(r["total_ms"] / r["busy_ms"], 3), GBps=round(gbps, 1),
-                                 frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4))
+                                 frac_hbm_peak=round(gbps / HBM_PEAK_GBPS, 4), frac_design=round(gbps_d / HBM_PEAK_GBPS, 4))
         nsteps_k = args.steps if "timed region" in kernel_source and "after" not in kernel_source else 2
         for v in kernels.values():
             v["launches_per_step"] = v["launches_per_step"] * args.steps / nsteps_k
@@ -272,13 +371,16 @@ def main():
         conc = r["total_ms"] / r["busy_ms"]              # the block's two mixers run on two streams: launches of this kernel overlap
         achieved = per_launch * conc                     # = all bytes of the kernel / time during which it was running
         # HBM traffic of the same kernel at the same shape from the committed PMC passes (cannot be read live)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["kernels"].get(f"{dom}:{args.dtype}")
-            if tj and tj["nseq"] == 3 * B and args.model == "DiffMa-L/2":
-                traffic = tj["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        traffic = traffic_src = None
+        for tf in ("r02_traffic.json", "r01_traffic.json"):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))["kernels"].get(f"{dom}:{args.dtype}")
+                if tj and tj["nseq"] == 3 * B and args.model == "DiffMa-L/2":
+                    traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_traffic.sh at this shape; not re-measured in this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
+        design_per_launch = r["design_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9 * conc
         res = {
             "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else ('250-step DDPM sampling' if args.sampler == 'ddpm250' else '50-step DDIM sampling')}; samples*steps/s)",
             "value": round(args.steps * B * world / elapsed, 3),
@@ -293,7 +395,12 @@ def main():
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_design": round(design_per_launch / HBM_PEAK_GBPS, 4),
+                         "design_bytes_per_launch": int(r["design_bytes_per_launch"]),
+                         "bytes_note": "algorithmic = SURVEY.md 8(d): 7*s B per (seq, channel, step) element + fp32 dB/dC for the backward, "
+                                       "4*s + B/C rows for the forward; design adds what this implementation moves on top (state "
+                                       "checkpoints every 4 steps, per-workgroup dB/dC partial rows, dA/dD/dbias partials)",
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
                          "concurrent_launches": round(conc, 3), "achieved_per_launch": round(per_launch, 1),
                          "timing": kernel_source + "; achieved = algorithmic bytes per launch / avg_us x concurrent_launches "
@@ -301,6 +408,13 @@ def main():
                                    "opt-in two-stream mode DIFFMA_OVERLAP_MIXERS=1 lets launches of the two mixers share the GPU)"},
             "kernels": kernels,
         }
+        res["config"]["world_size_seen_by_rccl"] = dist.get_world_size() if dist.is_initialized() else 1
+        if not args.no_extras:
+            if args.mode == "train" and world == 1 and not args.graph:      # extra steps on one rank only: never with peers waiting in an all-reduce
+                res["gemm"] = gemm_accounting(step, 1e3 * elapsed / args.steps)
+            if world == 1:
+                torch.cuda.empty_cache()
+                res["selective_scan_fn"] = scan_microbench(dev)
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":
             res["cpu_baseline"] = cpu_baseline(args, tokens)
     # RCCL writes its banner / warnings through C stdio (block-buffered on a pipe, NCCL_DEBUG=VERSION is set on the GPU boxes):

@@ -36,30 +36,38 @@ class GraphedDenoiser:
         self.sx, self.st = x.clone(), t.clone()
         self.sy, self.sy2, self.sw = y.clone(), y2.clone(), w.clone()
         self._cond_id = None
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):                       # lazy inits (hipBLASLt heuristics, allocator) happen outside the capture
-                self._run()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self.sout = self._run()
+        # everything below runs on the INPUT's device: torch.cuda.Stream() / torch.cuda.graph() use the current device, and
+        # a capture on cuda:0 of a model living on cuda:k records nothing (every replay would return the warm-up output)
+        with torch.cuda.device(x.device):
+            side = torch.cuda.Stream(device=x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):                   # lazy inits (hipBLASLt heuristics, allocator) happen outside the capture
+                    self._run()
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(self.graph):
+                self.sout = self._run()
 
     def _run(self):
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             return self.model(self.sx, self.st, y=self.sy, y2=self.sy2, w=self.sw)
 
+    def set_condition(self, y, y2, w):
+        """Copy the conditioning of a sampling run into the static buffers (also done by __call__ when it sees new tensors)."""
+        self.sy.copy_(y)
+        self.sy2.copy_(y2)
+        self.sw.copy_(w)
+        self._cond_id = tuple((t.data_ptr(), t._version) for t in (y, y2, w))
+
     def __call__(self, x, t, y=None, y2=None, w=None, **kw):
         self.sx.copy_(x)
         self.st.copy_(t)
-        cid = (y.data_ptr(), y2.data_ptr(), w.data_ptr())
-        if cid != self._cond_id:
-            self.sy.copy_(y)
-            self.sy2.copy_(y2)
-            self.sw.copy_(w)
-            self._cond_id = cid
-        self.graph.replay()
+        # storage AND version: a caller that refills the same buffers in place bumps _version
+        if tuple((c.data_ptr(), c._version) for c in (y, y2, w)) != self._cond_id:
+            self.set_condition(y, y2, w)
+        with torch.cuda.device(self.sx.device):
+            self.graph.replay()
         return self.sout
 
     def parameters(self):
@@ -90,6 +98,7 @@ class GraphedTrainStep:
         self.amp, self.decay = autocast_dtype, ema_decay
         self.sz, self.st = z.clone(), t.clone()
         self.sy, self.sy2, self.sw = y.clone(), y2.clone(), w.clone()
+        self._mixers = [m for net in (model, ema) if net is not None for m in net.modules() if hasattr(m, "A_log")]
         self._ep = [p for p in ema.parameters()] if ema is not None else []
         self._mp = [p for p in model.parameters()] if ema is not None else []
         # the warm-up iterations are real optimisation steps: remember the training state and put it back afterwards, so
@@ -98,16 +107,17 @@ class GraphedTrainStep:
             p_snap = [p.detach().clone() for p in model.parameters()]
             e_snap = [p.detach().clone() for p in self._ep]
             o_snap = {id(v): v.detach().clone() for st in optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):                       # lazy inits, GEMM solution lookups, optimizer state allocation
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        self.opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph):
-            self.sloss = self._step()
+        with torch.cuda.device(z.device):
+            side = torch.cuda.Stream(device=z.device)
+            side.wait_stream(torch.cuda.current_stream(z.device))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):                   # lazy inits, GEMM solution lookups, optimizer state allocation
+                    self._step()
+            torch.cuda.current_stream(z.device).wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.sloss = self._step()
         with torch.no_grad():
             for p, q in zip(model.parameters(), p_snap):
                 p.copy_(q)
@@ -136,5 +146,9 @@ class GraphedTrainStep:
         self.sy.copy_(y)
         self.sy2.copy_(y2)
         self.sw.copy_(w)
-        self.graph.replay()
+        with torch.cuda.device(self.sz.device):
+            self.graph.replay()
+        # a replayed optimizer updates A_log without bumping its version counter: drop the mixers' no-grad cache of -exp(A_log)
+        for m in self._mixers:
+            m.__dict__.pop("_A_cache", None)
         return self.sloss

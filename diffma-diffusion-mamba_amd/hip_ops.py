@@ -36,15 +36,15 @@ class KernelTimer:
     current stream).  bench.py installs one around its timed region; no host sync until `summary()`."""
 
     def __init__(self):
-        self.records = {}      # name -> list of (start_event, end_event, algorithmic_bytes)
+        self.records = {}      # name -> list of (start_event, end_event, algorithmic_bytes, design_bytes)
 
-    def launch(self, name, nbytes, fn):
+    def launch(self, name, nbytes, fn, design_bytes=None):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.setdefault(name, []).append((e0, e1, nbytes))
+        self.records.setdefault(name, []).append((e0, e1, nbytes, nbytes if design_bytes is None else design_bytes))
 
     def summary(self):
         """Per kernel: launches, avg_us / total_ms (per-launch durations, what a kernel trace reports), bytes_per_launch, and
@@ -58,11 +58,12 @@ class KernelTimer:
             if recs and base is None:
                 base = recs[0][0]
         for name, recs in self.records.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            nb = [n for _, _, n in recs]
-            busy = union_length((base.elapsed_time(a), base.elapsed_time(a) + d) for (a, _, _), d in zip(recs, ms))
+            ms = [r[0].elapsed_time(r[1]) for r in recs]
+            nb = [r[2] for r in recs]
+            db = [r[3] for r in recs]
+            busy = union_length((base.elapsed_time(r[0]), base.elapsed_time(r[0]) + d) for r, d in zip(recs, ms))
             out[name] = dict(launches=len(recs), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
-                             bytes_per_launch=sum(nb) / len(nb), busy_ms=busy)
+                             bytes_per_launch=sum(nb) / len(nb), design_bytes_per_launch=sum(db) / len(db), busy_ms=busy)
         return out
 
 
@@ -76,12 +77,14 @@ def set_timer(timer):
     return prev
 
 
-def _launch(name, args, tensor, nbytes):
+def _launch(name, args, tensor, nbytes, design_bytes=None):
+    """nbytes: ALGORITHMIC bytes of the launch (SURVEY.md 8d: what any implementation of the operator must move);
+    design_bytes: the bytes THIS implementation moves by design (algorithmic + checkpoints + partial rows), if different."""
     with torch.cuda.device(tensor.device):
         if _TIMER is None:
             _lib.call(name, args, _stream(tensor))
         else:
-            _TIMER.launch(name, nbytes, lambda: _lib.call(name, args, _stream(tensor)))
+            _TIMER.launch(name, nbytes, lambda: _lib.call(name, args, _stream(tensor)), design_bytes)
 
 
 def dtype_code(t: torch.Tensor) -> int:
@@ -132,6 +135,18 @@ def _ckpt_dtype_code(ckpt):
     return DM_BF16 if ckpt.dtype == torch.int32 else DM_F32
 
 
+def scan_fwd_algorithmic_bytes(S, Dm, L, N, es, es_bc, has_z=True):
+    """SURVEY.md 8(d) / BASELINE.md section 3: selective_scan_fn forward reads u, delta, z and writes out (4*s B per element),
+    reads the shared B, C rows and the constants A, D, delta_bias.  Nothing implementation-specific is counted."""
+    return (4 if has_z else 3) * S * Dm * L * es + 2 * S * N * L * es_bc + 4 * Dm * N + 8 * Dm
+
+
+def scan_bwd_algorithmic_bytes(S, Dm, L, N, es, has_z=True):
+    """the backward reads u, delta, z, dout and writes du, ddelta, dz (7*s B per element) plus fp32 dB, dC
+    (2*S*N*L*4).  Checkpoint reads, per-workgroup partial rows and the dA/dD/dbias partials are design traffic, not counted."""
+    return (7 if has_z else 5) * S * Dm * L * es + 2 * S * N * L * 4
+
+
 def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
              ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False):
@@ -166,11 +181,11 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.B_ss, a.B_sl, a.B_sn = Bm.stride()
     a.C_ss, a.C_sl, a.C_sn = Cm.stride()
     a.B_sg = a.C_sg = N
-    es = u.element_size()
-    nbytes = 4 * S * Dm * L * es - (0 if z is not None else S * Dm * L * es) + 2 * S * N * L * Bm.element_size() + 4 * Dm * N + 8 * Dm
+    nbytes = scan_fwd_algorithmic_bytes(S, Dm, L, N, u.element_size(), Bm.element_size(), z is not None)
+    design = nbytes
     if ckpt is not None:
-        nbytes += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * Dm * 4     # slots 1.. + slot 0 (the final state)
-    _launch("dm_selective_scan_fwd", a, u, nbytes)
+        design += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * Dm * 4     # slots 1.. + slot 0 (the final state)
+    _launch("dm_selective_scan_fwd", a, u, nbytes, design)
     return out
 
 
@@ -226,10 +241,10 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.B_sg = a.C_sg = N
     a.du_ss, a.du_sl, a.du_sd = du.stride()
     a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
-    es = u.element_size()
-    nbytes = (7 if z is not None else 5) * S * Dm * L * es + 2 * S * N * L * Bm.element_size() + S * L * nw * 2 * N * 4 \
+    nbytes = scan_bwd_algorithmic_bytes(S, Dm, L, N, u.element_size(), z is not None)
+    design = nbytes + 2 * S * N * L * Bm.element_size() + S * L * (nw - 1) * 2 * N * 4 + 4 * S * Dm * (N + 2) \
         + (scan_nchunk(L, ckpt_every) - 1 + (L % ckpt_every == 0)) * S * ckpt.shape[2] * Dm * 4   # slot 0 is read when L ends on a boundary
-    _launch("dm_selective_scan_bwd", a, u, nbytes)
+    _launch("dm_selective_scan_bwd", a, u, nbytes, design)
     if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype) in the caller's buffer: fp32 sum, ONE converting copy
         dbc_out.copy_(dBC.sum(dim=2))           # (sum(..., dtype=bf16, out=) would first cast the whole partial tensor)
         dBCs = dbc_out
@@ -250,7 +265,7 @@ def colsum(x):
     a.rows, a.cols = R, C
     setattr(a, "in", _ptr(x))
     a.out = _ptr(out)
-    _lib.call("dm_colsum_f32", a, _stream(x))
+    _launch("dm_colsum_f32", a, x, (R + 1) * C * 4)
     return out
 
 

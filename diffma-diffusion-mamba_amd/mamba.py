@@ -111,10 +111,10 @@ class Mamba(nn.Module):
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
-        if torch.is_grad_enabled():
-            A = -torch.exp(self.A_log.float())
+        if torch.is_grad_enabled() or (xz.is_cuda and torch.cuda.is_current_stream_capturing()):
+            A = -torch.exp(self.A_log.float())       # inside a capture A is recomputed IN the graph: replays follow A_log
         else:                                        # inference: A only changes when A_log does (two tiny kernels per call otherwise)
-            cache = getattr(self, "_A_cache", None)
+            cache = getattr(self, "_A_cache", None)  # (hipGraph replays of an optimizer do not bump _version: GraphedTrainStep drops the cache)
             if cache is None or cache[0] != self.A_log._version or cache[1].device != self.A_log.device:
                 cache = (self.A_log._version, -torch.exp(self.A_log.detach().float()))
                 self._A_cache = cache

@@ -195,6 +195,22 @@ class EfficientVMamba_MambaBlock(_BaselineMambaBlock):
         super().__init__(D_dim, E_dim, dt_rank, dim_inner, d_state, use_mamba2)
 
 
+def make_ddp_comm_hook(grad_compression="none", join_streams=False):
+    """DDP communication hook factory (train.wrap_ddp): optionally join the two mixer streams first, then all-reduce the bucket
+    (mean over ranks) either as it is (fp32, the reference's behaviour) or as a bf16 / fp16 copy that is cast back afterwards."""
+    from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
+
+    reduce_hook = {"none": default_hooks.allreduce_hook, "bf16": default_hooks.bf16_compress_hook,
+                   "fp16": default_hooks.fp16_compress_hook}[grad_compression]
+
+    def hook(process_group, bucket):
+        if join_streams:
+            Spiral_MambaBlock.join_streams()
+        return reduce_hook(process_group, bucket)
+
+    return hook
+
+
 def ddp_join_streams_hook(process_group, bucket):
     """DDP communication hook for models whose blocks run their mixers on two streams: join the streams, then the stock
     all-reduce (mean over ranks).  Register with `ddp.register_comm_hook(process_group_or_None, ddp_join_streams_hook)`."""

@@ -35,6 +35,7 @@ def main(args):
     world = dist.get_world_size() if dist.is_initialized() else 1
     device = torch.device("cuda", rank % torch.cuda.device_count()) if torch.cuda.is_available() else torch.device("cpu")
     if device.type == "cuda":
+        torch.cuda.set_device(device)      # streams, graph capture and the C-ABI launches all follow the current device
         from .gemm_tuning import enable_tuned_gemms
         enable_tuned_gemms()
     latent = args.image_size // 8
@@ -56,6 +57,7 @@ def main(args):
     g = torch.Generator(device=device).manual_seed(args.seed * world + rank)
     mk = lambda *s: torch.randn(*s, generator=g, device=device)
     out = []
+    graphed = None                          # shapes are identical for every batch: one capture serves the whole run
     for b in range(int(args.get("num_batches", 1))):
         z = mk(n, 4, latent, latent)
         if ct_encoder is not None:                     # soft mask + token conditioning from the CT latent (reference sample.py:104)
@@ -67,8 +69,11 @@ def main(args):
         loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
         denoiser = model.forward
         if device.type == "cuda" and not args.get("no_graph", False):
-            from .graphed import GraphedDenoiser      # shapes are static over all steps: capture once, replay per step
-            denoiser = GraphedDenoiser(model, z, torch.zeros(n, device=device, dtype=torch.long), kw["y"], kw["y2"], kw["w"])
+            if graphed is None:
+                from .graphed import GraphedDenoiser  # shapes are static over all steps: capture once, replay per step
+                graphed = GraphedDenoiser(model, z, torch.zeros(n, device=device, dtype=torch.long), kw["y"], kw["y2"], kw["w"])
+            graphed.set_condition(kw["y"], kw["y2"], kw["w"])
+            denoiser = graphed
         samples = loop(denoiser, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=device)
         out.append(samples.cpu())
     torch.save(torch.cat(out), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))

@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import logging
+import math
 import os
 from copy import deepcopy
 from glob import glob
@@ -98,6 +99,26 @@ def build_ct_encoder(args, latent, device):
     return ct.eval().requires_grad_(False)
 
 
+DDP_BUCKET_MB = 64           # 357 MB of fp32 gradients for DiffMa-L/2 -> 6 buckets, each large enough to run at xGMI link speed
+
+
+def wrap_ddp(model, device, grad_compression="none"):
+    """The one place DDP is configured -- train.py and bench.py both call it, so a scaling number measures what training uses.
+    Gradients only (reference train.py:153); buckets are views of the gradients, the graph is static (same parameters used
+    every step), and the communication hook (a) joins the two mixer streams when the opt-in two-stream mode is on and
+    (b) optionally all-reduces bf16 / fp16 copies of the buckets (`grad_compression`: "none" | "bf16" | "fp16"; halves the
+    bytes on the xGMI links, the sum is still accumulated by RCCL in that dtype -- opt-in, off by default)."""
+    if grad_compression not in ("none", "bf16", "fp16"):
+        raise ValueError(f"grad_compression={grad_compression!r}")
+    ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
+              bucket_cap_mb=DDP_BUCKET_MB, static_graph=True)
+    from .mamba_block import Spiral_MambaBlock, make_ddp_comm_hook
+    join = device.type == "cuda" and Spiral_MambaBlock.overlap_mixers      # both streams write gradients
+    if join or grad_compression != "none":
+        ddp.register_comm_hook(None, make_ddp_comm_hook(grad_compression, join))
+    return ddp
+
+
 def main(args):
     backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
@@ -146,11 +167,7 @@ def main(args):
     if use_graph:
         ddp = model                                  # one process: no reducer hooks inside the captured backward
     else:
-        ddp = DDP(model, device_ids=[device.index] if device.type == "cuda" else None, gradient_as_bucket_view=True,
-                  bucket_cap_mb=64)
-        from .mamba_block import Spiral_MambaBlock, ddp_join_streams_hook
-        if device.type == "cuda" and Spiral_MambaBlock.overlap_mixers:   # opt-in two-stream mode: both streams write gradients
-            ddp.register_comm_hook(None, ddp_join_streams_hook)
+        ddp = wrap_ddp(model, device, grad_compression=str(args.get("grad_compression", "none")))
     diffusion = create_diffusion(timestep_respacing="")
     logger.info(f"DiffMa Parameters: {sum(p.numel() for p in model.parameters()):,}")
     logger.info(f"Use half-precision training? {args.autocast}")
@@ -190,32 +207,45 @@ def main(args):
                 log_steps += 1
                 if train_steps % args.log_every == 0:           # the only host sync of the graphed loop
                     lv = loss.item()
-                    if lv != lv:
+                    if not math.isfinite(lv):
                         raise FloatingPointError(f"non-finite loss at step {train_steps} (a graphed step cannot skip its update)")
                     running_loss = lv * log_steps               # the log line shows the latest loss instead of a running mean
             else:
                 with torch.autocast(device.type, dtype=amp, enabled=amp is not None):
                     loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
-                bad = (~torch.isfinite(loss.detach())).float()
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)  # every rank takes the same decision
-                scaler.scale(loss).backward()                # always run backward: keeps DDP's bucket all-reduces matched
-                if bad.item() > 0:
+                # [bad flag, loss value] travel in ONE all-reduce and ONE host read per step (the reference reads loss.item() too)
+                lv = loss.detach().float()
+                flag = torch.stack([(~torch.isfinite(lv)).float(), torch.nan_to_num(lv, nan=0.0, posinf=0.0, neginf=0.0)])
+                if world > 1:
+                    dist.all_reduce(flag[:1], op=dist.ReduceOp.MAX)      # every rank takes the same decision
+                bad_host, loss_host = flag.tolist()
+                bad = bad_host > 0
+                if bad:
                     logger.info("nan......      ignore losses......")
-                    opt.zero_grad(set_to_none=True)
-                    continue
-                if train_steps % args.accumulation_steps == 0:
-                    scaler.step(opt)                         # fp16: unscales, skips the update on inf/nan gradients
-                    scaler.update()
-                    update_ema(ema, model)
-                    opt.zero_grad(set_to_none=True)
-                running_loss += loss.item()
-                log_steps += 1
-                train_steps += 1
+                    # backward still runs (it keeps DDP's bucket all-reduces matched across ranks); what it adds is thrown
+                    # away, what earlier good micro-batches accumulated is put back
+                    kept = [None if p_.grad is None else p_.grad.detach().clone() for p_ in model.parameters()]
+                    scaler.scale(loss).backward()
+                    for p_, g_ in zip(model.parameters(), kept):
+                        if g_ is None:
+                            p_.grad = None
+                        else:
+                            p_.grad.copy_(g_)
+                else:
+                    scaler.scale(loss).backward()
+                    if train_steps % args.accumulation_steps == 0:
+                        scaler.step(opt)                     # fp16: unscales, skips the update on inf/nan gradients
+                        scaler.update()
+                        update_ema(ema, model)
+                        opt.zero_grad(set_to_none=True)
+                    running_loss += loss_host
+                    log_steps += 1
+                train_steps += 1                             # a skipped step still counts: --max-steps / ckpt / log checks run
             if train_steps % args.log_every == 0:
                 if device.type == "cuda":
                     torch.cuda.synchronize()
-                steps_per_sec = log_steps / (time() - start_time)
-                avg = torch.tensor(running_loss / log_steps, device=device)
+                steps_per_sec = max(log_steps, 1) / (time() - start_time)
+                avg = torch.tensor(running_loss / max(log_steps, 1), device=device)
                 dist.all_reduce(avg, op=dist.ReduceOp.SUM)
                 pct = local_batch * item / data.n * 100
                 logger.info(f"({pct:.1f}%) (step={train_steps:07d}) Train Loss: {avg.item() / world:.4f}, Train Steps/Sec: {steps_per_sec:.2f}")
@@ -244,6 +274,8 @@ def cli(argv=None):
     p.add_argument("--use-mamba2", action="store_true")
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning instead of datasets + frozen encoders")
     p.add_argument("--max-steps", type=int, default=None)
+    p.add_argument("--grad-compression", default=None, choices=["none", "bf16", "fp16"],
+                   help="all-reduce 16-bit copies of the DDP gradient buckets (opt-in; default none = fp32 like the reference)")
     p.add_argument("--graph-train", action="store_true", help="replay the whole optimisation step from a hipGraph (1 GPU; for small batches)")
     p.add_argument("--config", type=str, required=True)
     a = p.parse_args(argv)

@@ -1,0 +1,259 @@
+"""GPU runs of the harness rows (a12 sampling loops, a13 train.py:main, a14 sample.py:main) and of the
+"next" row f1 (CT_Encoder with the reference's shipped weights feeding the denoiser), each against the CPU oracle or a
+golden fixture -- never the HIP path against itself.
+
+Sampling-loop parity: the SAME product loop is run twice with the SAME supplied per-step noise -- on the GPU with the HIP
+denoiser, on the CPU with the fp64 oracle denoiser (oracle/model_ref.py, pinned by G5/G10) -- tolerance rel-L2 <= 1e-3 in
+fp32 (the diffusion arithmetic itself is pinned by G3 on CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+class NoiseTape:
+    """Replacement for th.randn_like inside diffusion/gaussian_diffusion.py: call i returns tape[i] (generated once on the
+    CPU), on the device / dtype of the argument, so a GPU loop and a CPU loop see identical noise."""
+
+    def __init__(self, shape, n, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.tape = [torch.randn(*shape, generator=g) for _ in range(n)]
+        self.i = 0
+
+    def rewind(self):
+        self.i = 0
+
+    def __call__(self, x):
+        t = self.tape[self.i].to(device=x.device, dtype=x.dtype)
+        self.i += 1
+        return t
+
+
+def _g5(gpu):
+    from diffma_amd.model import DiffMa
+
+    g = np.load(os.path.join(G, "g5_tiny_diffma.npz"))
+    sd = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")}
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16)
+    net.load_state_dict(sd)
+    net = net.to(gpu).eval()
+    inp = {k: torch.from_numpy(g[k]) for k in ("x", "t", "y", "y2", "w")}
+    return g, sd, net, inp
+
+
+def _oracle_denoiser(sd, patch, depth):
+    from oracle.model_ref import diffma_forward_ref
+
+    def model(x, t, y=None, y2=None, w=None, **kw):
+        return diffma_forward_ref(sd, x.double(), t, y.double(), y2.double(), w.double(), patch_size=patch, depth=depth,
+                                  dtype=torch.float64).float()
+    return model
+
+
+@pytest.mark.parametrize("sampler", ["ddpm", "ddim", "ddim_eta1"])
+def test_sampling_loops_match_oracle_driven_loop(gpu, monkeypatch, sampler):
+    """p_sample_loop("10") / ddim_sample_loop (reference gaussian_diffusion.py:419-511, 513-680) on the G5 net: HIP denoiser on
+    the GPU vs the fp64 oracle denoiser on the CPU, same start latent, same per-step noise."""
+    import diffma_amd.diffusion.gaussian_diffusion as gd
+    from diffma_amd.diffusion import create_diffusion
+
+    g, sd, net, inp = _g5(gpu)
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(5))
+    tape = NoiseTape(z.shape, 16, seed=6)
+    monkeypatch.setattr(gd.th, "randn_like", tape)
+    d = create_diffusion("10" if sampler == "ddpm" else "ddim10")
+    kw_cpu = dict(y=inp["y"], y2=inp["y2"], w=inp["w"])
+    kw_gpu = {k: v.to(gpu) for k, v in kw_cpu.items()}
+    extra = {} if sampler == "ddpm" else {"eta": 1.0 if sampler == "ddim_eta1" else 0.0}
+    loop = (lambda dd: dd.p_sample_loop) if sampler == "ddpm" else (lambda dd: dd.ddim_sample_loop)
+    with torch.no_grad():
+        got = loop(d)(net.forward, z.shape, z.to(gpu), clip_denoised=False, model_kwargs=kw_gpu, device=gpu, **extra)
+        used = tape.i
+        tape.rewind()
+        ref = loop(d)(_oracle_denoiser(sd, 2, 4), z.shape, z.clone(), clip_denoised=False, model_kwargs=kw_cpu, device="cpu", **extra)
+    assert used == tape.i == 10
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) <= 1e-3, rel_l2(got, ref)
+    assert rel_l2(got, z) > 0.05                                  # the loop did move the latent
+
+
+def _write_s7_checkpoint(path, seed=0):
+    """A DiffMa-S/7 checkpoint in the reference's format ({"model","ema",...}, train.py:291-303) whose zero-initialised tensors
+    are re-randomised (the stock init makes the denoiser output exactly 0)."""
+    from diffma_amd.model import DiffMa_models
+
+    torch.manual_seed(seed)
+    net = DiffMa_models["DiffMa-S/7"](input_size=28, dt_rank=16, d_state=16)
+    gen = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.requires_grad and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+            if name.endswith("A_log") or name.endswith(".D"):
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    torch.save({"model": sd, "ema": sd, "args": {}}, path)
+    return sd, net.depth, net.patch_size
+
+
+@pytest.mark.parametrize("ddim,no_graph", [(False, True), (False, False), (True, True), (True, False)])
+def test_sample_main_matches_oracle_driven_loop(gpu, monkeypatch, tmp_path, ddim, no_graph):
+    """sample.py:main (reference sample.py:29-115) end to end on the GPU: checkpoint load (EMA entry), conditioning, 10-step
+    respaced DDPM or DDIM loop, eager and hipGraph-replayed, two batches -- against the same loop on the CPU with the oracle
+    denoiser, same latents / conditioning / per-step noise."""
+    import diffma_amd.diffusion.gaussian_diffusion as gd
+    from diffma_amd import sample as sample_mod
+    from diffma_amd.config import Config
+    from diffma_amd.diffusion import create_diffusion
+
+    ck = str(tmp_path / "s7.pt")
+    sd, depth, patch = _write_s7_checkpoint(ck)
+    n, nb, steps, seed = 2, 2, 10, 3
+    tape = NoiseTape((n, 4, 28, 28), nb * steps, seed=11)
+    monkeypatch.setattr(gd.th, "randn_like", tape)
+    args = Config(model="DiffMa-S/7", image_size=224, dt_rank=16, d_state=16, ckpt=ck, load_ckpt_type="ema", save_dir=str(tmp_path / "out"),
+                  seed=seed, sample_global_batch_size=n, sample_num_steps=steps, num_batches=nb, ddim=ddim, no_graph=no_graph, synthetic=True)
+    try:
+        out = sample_mod.main(args)
+    finally:
+        torch.set_grad_enabled(True)            # sample.main disables grad globally, like the reference script (sample.py:31)
+    assert len(out) == nb and tape.i == nb * steps
+    saved = torch.load(os.path.join(args.save_dir, "latents_rank0.pt"))
+    assert torch.equal(saved, torch.cat(out))
+    # the same draws sample.main made (generator seeded seed*world+rank on the device, z then y, y2, w per batch)
+    gen = torch.Generator(device=gpu).manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=gen, device=gpu)
+    d = create_diffusion(f"ddim{steps}" if ddim else str(steps))
+    model = _oracle_denoiser(sd, patch, depth)
+    tape.rewind()
+    for b in range(nb):
+        z = mk(n, 4, 28, 28)
+        kw = dict(y=mk(n, 512).cpu(), y2=mk(n, 16, 512).cpu(), w=torch.sigmoid(mk(n, 16, 1)).cpu())
+        loop = d.ddim_sample_loop if ddim else d.p_sample_loop
+        with torch.no_grad():
+            ref = loop(model, z.shape, z.cpu(), clip_denoised=False, model_kwargs=kw, device="cpu")
+        assert torch.isfinite(out[b]).all()
+        assert rel_l2(out[b], ref) <= 1e-3, (b, rel_l2(out[b], ref))
+
+
+def _dist_env(monkeypatch, port):
+    for k, v in dict(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0").items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16", "bf16-graph", "bf16-gradcomp"])
+def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
+    """train.py:main (reference train.py:90-311) on one GPU through RCCL + DDP: DiffMa-S/2 (196 tokens) on synthetic latents,
+    bf16 autocast (default), fp32, the reference's fp16 + GradScaler mode, the graphed step, and the opt-in bf16 gradient
+    all-reduce.  Checks: step count, the reference-format checkpoint, finite weights that moved, EMA = its recurrence."""
+    import socket
+
+    from diffma_amd import train as train_mod
+    from diffma_amd.config import Config
+    from diffma_amd.model import DiffMa_models
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    _dist_env(monkeypatch, port)
+    cfg = Config(model="DiffMa-S/2", image_size=224, dt_rank=16, d_state=16, global_batch_size=4, global_seed=0, lr=1e-4, lr_=1e-4,
+                 epochs=1, accumulation_steps=1, log_every=1, ckpt_every=3, results_dir=str(tmp_path / "res"),
+                 init_from_pretrain_ckpt=False, pretrain_ckpt_path="", init_train_steps=0, synthetic=True, synthetic_samples=64,
+                 max_steps=3, autocast=mode != "fp32", amp_dtype="fp16" if mode == "fp16" else "bf16",
+                 graph_train=mode == "bf16-graph", grad_compression="bf16" if mode == "bf16-gradcomp" else "none")
+    assert train_mod.main(cfg) == 3
+    ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith("0000003.pt")]
+    assert len(ck) == 1
+    sd = torch.load(ck[0], map_location="cpu", weights_only=False)
+    assert set(sd) == {"model", "ema", "opt", "args"}
+    torch.manual_seed(0)                                                   # the seed rule of train.py:99 at world 1, rank 0
+    init = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16).state_dict()
+    k = "final_layer.linear.weight"                                        # zero-initialised: every step moves it by ~lr
+    assert all(torch.isfinite(v).all() for v in sd["model"].values())
+    moved = (sd["model"][k] - init[k]).abs().max().item()
+    assert 0.5e-4 < moved < 4e-4, moved
+    # EMA after 3 steps from a decay-0 copy of the init: 0.999^3 w0 + sum_i 0.001 * 0.999^(3-i) w_i; bounded by the model's travel
+    e = (sd["ema"][k] - init[k]).abs().max().item()
+    assert 0 < e < moved * 0.01, (e, moved)
+    net = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16)
+    net.load_state_dict(sd["ema"], strict=True)
+
+
+def test_ct_encoder_pretrained_feeds_denoiser_on_device(gpu):
+    """the CT_Encoder with the reference's shipped weights (G8b) runs on the device and its (w, y2) drive the G5
+    denoiser -- HIP output vs the oracle denoiser fed the fixture's (w, y2)."""
+    import torch.nn.functional as F
+
+    from diffma_amd.ct_encoder import CT_Encoder
+
+    g8 = np.load(os.path.join(G, "g8b_ct_encoder_pretrained.npz"))
+    tag = "brain.ema"
+    ct = CT_Encoder(img_size=28, patch_size=2, in_channels=4, embed_dim=512, contain_mask_token=True).eval()
+    ct.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g8[k]) for k in g8.files if k.startswith(tag + ".sd.")}, strict=True)
+    ct = ct.to(gpu)
+    with torch.no_grad():
+        w, y2 = ct(torch.from_numpy(g8[f"{tag}.x"]).to(gpu))
+    np.testing.assert_allclose(w.cpu().numpy(), g8[f"{tag}.w"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(y2.cpu().numpy(), g8[f"{tag}.y2"], rtol=1e-3, atol=1e-4)
+    # the G5 net has 16 tokens x 64 features: feed it a 16-token, 64-feature window of the encoder outputs
+    g, sd, net, inp = _g5(gpu)
+    w16, y216 = w[:, :16].contiguous(), F.layer_norm(y2[:, :16, :64], (64,)).contiguous()
+    with torch.no_grad():
+        out = net(inp["x"].to(gpu), inp["t"].to(gpu), y=inp["y"].to(gpu), y2=y216, w=w16)
+    w_ref = torch.from_numpy(g8[f"{tag}.w"])[:, :16]
+    y2_ref = F.layer_norm(torch.from_numpy(g8[f"{tag}.y2"])[:, :16, :64].double(), (64,))
+    ref = _oracle_denoiser(sd, 2, 4)(inp["x"], inp["t"], y=inp["y"], y2=y2_ref, w=w_ref)
+    assert rel_l2(out, ref) <= 1e-3, rel_l2(out, ref)
+
+
+def test_train_step_adamw_ema_matches_reference_on_device(gpu):
+    """G11 on the HIP path (fp32): two steps of training_losses -> AdamW(1e-4, wd 0) -> update_ema from the G5 state; gradients,
+    weights and EMA against the reference loop's (operator = fp64 oracle)."""
+    import copy
+
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.train import update_ema
+
+    g5, sd, net, inp = _g5(gpu)
+    g = np.load(os.path.join(G, "g11_train_step.npz"))
+    net.train()
+    ema = copy.deepcopy(net).requires_grad_(False)
+    update_ema(ema, net, decay=0)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True)
+    d = create_diffusion("")
+    z, nz, tt = (torch.from_numpy(g5[k]).to(gpu) for k in ("loss_z", "loss_noise", "loss_t"))
+    kw = {k: inp[k].to(gpu) for k in ("y", "y2", "w")}
+    for step in range(2):
+        loss = d.training_losses(net, z, tt, kw, noise=nz)["loss"].mean()
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            for k in (f[len("step0.grad."):] for f in g.files if f.startswith("step0.grad.")):
+                assert rel_l2(net.get_parameter(k).grad, torch.from_numpy(g[f"step0.grad.{k}"])) <= 5e-3, k
+        opt.step()
+        update_ema(ema, net)
+        assert abs(float(loss.detach()) - float(g[f"step{step}.loss"])) <= 2e-3 * abs(float(g[f"step{step}.loss"]))
+        for f in g.files:
+            if f.startswith(f"step{step}.model."):
+                k = f[len(f"step{step}.model."):]
+                ref, got, w0 = torch.from_numpy(g[f]), net.get_parameter(k).detach().cpu(), sd[k]
+                # Adam's step is -lr * m/(sqrt(v)+eps): elements whose gradient is far above eps moved by a full lr
+                gk = f"step0.grad.{k}"
+                solid = torch.from_numpy(np.abs(g[gk]) > 1e-4) if (step == 0 and gk in g.files) else (ref - w0).abs() > 0.9e-4 * (step + 1)
+                if int(solid.sum()) == 0:
+                    continue
+                bad = ((got[solid] - ref[solid]).abs() > 2e-5).float().mean().item()
+                assert bad <= 0.01, (k, bad)
+            elif f.startswith(f"step{step}.ema."):
+                k = f[len(f"step{step}.ema."):]
+                torch.testing.assert_close(ema.get_parameter(k).detach().cpu(), torch.from_numpy(g[f]), rtol=0, atol=3e-7, msg=lambda m, k=k: f"ema {k}: {m}")

@@ -344,3 +344,130 @@ def test_product_baseline_models_have_reference_state_dict_layout(tag):
         DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, block_type="DiT")
     with pytest.raises(NotImplementedError):      # raises TypeError in the reference
         DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, block_type="efficientVMamba", use_mamba2=True)
+
+
+# ---- G10: the operator arithmetic the reference itself holds (Mamba.step / Mamba2.step run token by token) ---------------
+# block/mamba.py:405-448, block/mamba2.py:715-775.  This is the pin of the ORACLE's operator restatement: no oracle function
+# took part in generating G10.  fp64 throughout; A is taken from the fixture (step() rounds A_log to fp32 before the exp).
+G10_M1 = ["m1.a", "m1.b", "m1.c"]
+G10_M2 = ["m2.a", "m2.b", "m2.c", "m2.d"]
+
+
+def g10_case(tag):
+    g = load("g10_reference_step.npz")
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+    extra = {k[len(tag) + 1:]: g[k] for k in g.files if k.startswith(tag + ".") and ".sd." not in k}
+    return sd, extra
+
+
+@pytest.mark.parametrize("tag", G10_M1)
+def test_oracle_mamba_inner_matches_reference_step(tag):
+    from oracle.mamba_ref import mamba_inner_ref, selective_scan_ref, causal_conv1d_ref
+
+    sd, e = g10_case(tag)
+    hidden, want = torch.from_numpy(e["hidden"]), torch.from_numpy(e["out"])
+    A = torch.from_numpy(e["A"]).double()
+    xz = torch.einsum("ed,bld->bel", sd["in_proj.weight"], hidden)                  # (B, 2Din, L), block/mamba.py:333-337
+    got = mamba_inner_ref(xz, sd["conv1d.weight"], sd["conv1d.bias"], sd["x_proj.weight"], sd["dt_proj.weight"],
+                          sd["out_proj.weight"], None, A, None, None, sd["D"], delta_bias=sd["dt_proj.bias"], delta_softplus=True)
+    assert got.dtype == torch.float64
+    err = float((got - want).abs().max())
+    assert err <= 1e-9, f"oracle mamba_inner_ref vs reference Mamba.step(): max abs {err}"
+    # the same through A_log (exp in fp64 instead of the reference's fp32 exp): the 1e-6 band VERDICT r1 measured
+    got2 = mamba_inner_ref(xz, sd["conv1d.weight"], sd["conv1d.bias"], sd["x_proj.weight"], sd["dt_proj.weight"],
+                           sd["out_proj.weight"], None, -torch.exp(sd["A_log"]), None, None, sd["D"],
+                           delta_bias=sd["dt_proj.bias"], delta_softplus=True)
+    assert float((got2 - want).abs().max()) <= 1e-6
+    # selective_scan_ref on its own, with return_last_state, against the reference's final ssm_state
+    Din = sd["D"].shape[0]
+    R = sd["dt_proj.weight"].shape[1]
+    N = A.shape[1]
+    xc = causal_conv1d_ref(xz[:, :Din], sd["conv1d.weight"].reshape(Din, -1), sd["conv1d.bias"], activation="silu")
+    x_dbl = torch.einsum("bdl,ed->ble", xc, sd["x_proj.weight"])
+    delta = torch.einsum("blr,dr->bdl", x_dbl[..., :R], sd["dt_proj.weight"])
+    _, last = selective_scan_ref(xc, delta, A, x_dbl[..., R:R + N].permute(0, 2, 1), x_dbl[..., R + N:].permute(0, 2, 1), sd["D"],
+                                 z=xz[:, Din:], delta_bias=sd["dt_proj.bias"], delta_softplus=True, return_last_state=True)
+    assert float((last - torch.from_numpy(e["last_state"])).abs().max()) <= 1e-9
+
+
+@pytest.mark.parametrize("tag", G10_M2)
+def test_oracle_mamba2_combined_matches_reference_step(tag):
+    from oracle.mamba2_ref import mamba_split_conv1d_scan_combined_ref
+
+    sd, e = g10_case(tag)
+    hidden, want = torch.from_numpy(e["hidden"]), torch.from_numpy(e["out"])
+    A = torch.from_numpy(e["A"]).double()
+    rms = bool(int(e["rmsnorm"]))
+    zxbcdt = hidden @ sd["in_proj.weight"].t()
+    got = mamba_split_conv1d_scan_combined_ref(
+        zxbcdt, sd["conv1d.weight"], sd["conv1d.bias"], sd["dt_bias"], A, sd["D"], chunk_size=256, activation="silu",
+        rmsnorm_weight=sd["norm.weight"] if rms else None, rmsnorm_eps=1e-5, outproj_weight=sd["out_proj.weight"], outproj_bias=None,
+        headdim=int(e["headdim"]), ngroups=1, norm_before_gate=False)
+    err = float((got - want).abs().max())
+    assert err <= 1e-9, f"oracle Mamba-2 operator vs reference Mamba2.step(): max abs {err}"
+
+
+# ---- G8b: CT_Encoder with the reference's shipped weights (pretrain_ct_vision_embedder/*.pt, "ema" entry, train.py:166-168) ----
+@pytest.mark.parametrize("name", ["brain", "pelvis"])
+def test_ct_encoder_loads_reference_pretrained_weights(name):
+    from diffma_amd.ct_encoder import CT_Encoder
+
+    g = load("g8b_ct_encoder_pretrained.npz")
+    tag = f"{name}.ema"
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + ".sd.")}
+    assert len(sd) == 9
+    ct = CT_Encoder(img_size=28, patch_size=2, in_channels=4, embed_dim=512, contain_mask_token=True).eval()
+    ct.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        w, y2 = ct(torch.from_numpy(g[f"{tag}.x"]))
+    np.testing.assert_allclose(w.numpy(), g[f"{tag}.w"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y2.numpy(), g[f"{tag}.y2"], rtol=1e-4, atol=2e-5)
+
+
+# ---- G11: one optimisation step of the reference loop (training_losses -> AdamW(1e-4, wd 0) -> the reference's update_ema) ----
+def test_train_step_adamw_ema_matches_reference(monkeypatch):
+    """Product model (operator = the CPU oracle, injected by the test like in test_host_cpu.py) + product diffusion + product
+    update_ema against G11.  Adam's first step is -lr * g / (|g| + eps): elements whose gradient is ~eps are excluded."""
+    import copy
+
+    import diffma_amd.mamba as mamba_mod
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa
+    from diffma_amd.train import update_ema
+    from tests.test_host_cpu import _oracle_spiral_ssm
+
+    monkeypatch.setattr(mamba_mod, "spiral_ssm", _oracle_spiral_ssm)
+    g5, g = load("g5_tiny_diffma.npz"), load("g11_train_step.npz")
+    init = {k[3:]: torch.from_numpy(g5[k]) for k in g5.files if k.startswith("sd.")}
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16)
+    net.load_state_dict(init)
+    net.train()
+    ema = copy.deepcopy(net).requires_grad_(False)
+    update_ema(ema, net, decay=0)
+    opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0)
+    d = create_diffusion("")
+    z, nz, tt = (torch.from_numpy(g5[k]) for k in ("loss_z", "loss_noise", "loss_t"))
+    kw = {k: torch.from_numpy(g5[k]) for k in ("y", "y2", "w")}
+    for step in range(2):
+        loss = d.training_losses(net, z, tt, kw, noise=nz)["loss"].mean()
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            for k in (f[len("step0.grad."):] for f in g.files if f.startswith("step0.grad.")):
+                ref = torch.from_numpy(g[f"step0.grad.{k}"]).double()
+                got = net.get_parameter(k).grad.double()
+                assert float((got - ref).norm() / ref.norm().clamp_min(1e-30)) <= 1e-4, k
+        opt.step()
+        update_ema(ema, net)
+        assert abs(float(loss.detach()) - float(g[f"step{step}.loss"])) <= 1e-5 * abs(float(g[f"step{step}.loss"]))
+        for f in g.files:
+            if f.startswith(f"step{step}.model."):
+                k = f[len(f"step{step}.model."):]
+                ref, got, w0 = torch.from_numpy(g[f]), net.get_parameter(k).detach(), init[k]
+                solid = (ref - w0).abs() > 0.5e-4 * (step + 1)        # elements that took (almost) a full lr-sized step
+                if step == 0 and f"step0.grad.{k}" in g.files:
+                    solid = torch.from_numpy(np.abs(g[f"step0.grad.{k}"]) > 1e-5)
+                torch.testing.assert_close(got[solid], ref[solid], rtol=0, atol=2e-6, msg=lambda m, k=k: f"{k}: {m}")
+            elif f.startswith(f"step{step}.ema."):
+                k = f[len(f"step{step}.ema."):]
+                torch.testing.assert_close(ema.get_parameter(k).detach(), torch.from_numpy(g[f]), rtol=0, atol=1e-7, msg=lambda m, k=k: f"ema {k}: {m}")

@@ -97,6 +97,48 @@ def test_ddp_training_two_ranks_gloo(tmp_path):
     assert not torch.equal(sd["model"][some], sd["ema"][some])
 
 
+def _hook_worker(rank, world, port, compression, out_path):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    from diffma_amd.train import wrap_ddp
+
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.SiLU(), torch.nn.Linear(40, 8))
+    ddp = wrap_ddp(net, torch.device("cpu"), grad_compression=compression)
+    x = torch.randn(5, 24, generator=torch.Generator().manual_seed(100 + rank))
+    for _ in range(2):                                   # static_graph: the second iteration runs the rebuilt buckets
+        net.zero_grad(set_to_none=True)
+        ddp(x).square().sum().backward()
+    if rank == 0:
+        torch.save({k: p.grad.clone() for k, p in net.named_parameters()}, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compression", ["none", "bf16", "fp16"])
+def test_ddp_wrapper_and_gradient_compression_hook_two_ranks_gloo(compression, tmp_path):
+    """train.wrap_ddp (the wrapper bench.py shares): the all-reduced gradient equals the mean of the per-rank gradients --
+    exactly for fp32 buckets, within the 16-bit rounding for the opt-in compressed all-reduce."""
+    out_path = str(tmp_path / "grads.pt")
+    mp.spawn(_hook_worker, args=(2, _free_port(), compression, out_path), nprocs=2, join=True)
+    got = torch.load(out_path)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(24, 40), torch.nn.SiLU(), torch.nn.Linear(40, 8))
+    want = None
+    for r in range(2):
+        net.zero_grad(set_to_none=True)
+        net(torch.randn(5, 24, generator=torch.Generator().manual_seed(100 + r))).square().sum().backward()
+        gr = {k: p.grad.clone() for k, p in net.named_parameters()}
+        want = gr if want is None else {k: (want[k] + gr[k]) / 2 for k in gr}
+    tol = {"none": dict(rtol=1e-6, atol=1e-6), "bf16": dict(rtol=2e-2, atol=2e-2), "fp16": dict(rtol=2e-3, atol=2e-3)}[compression]
+    for k in want:
+        torch.testing.assert_close(got[k], want[k], **tol, msg=lambda m, k=k: f"{k}: {m}")
+
+
 def test_synthetic_batches_through_ct_encoder():
     """`synthetic_ct_encoder: true`: the soft mask and token conditioning of the synthetic stream come from a CT_Encoder
     (reference train.py:239-240) instead of being drawn directly."""

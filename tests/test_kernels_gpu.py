@@ -248,11 +248,17 @@ def test_token_merge_exact(gpu):
     assert torch.equal(out2, (slabs[0] + slabs[1]) + slabs[2])
 
 
-def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None):
+def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None, a_shared=False, dout_per_seq=False):
+    """a_shared: A[d, :] is one value per channel and the kernels run their DM_FLAG_A_SHARED form (one exp per channel-step, the
+    Mamba-2 call pattern); dout_per_seq: the incoming gradient is per direction [S, L, Dm] in token order, read through
+    out_row_index (DM_FLAG_DOUT_PER_SEQ) instead of one merged gradient per batch element."""
     from diffma_amd import hip_ops
     from oracle.mamba_ref import selective_scan_ref
 
     host, d = _inputs(S, L, Dm, N, dtype, seed=seed, dev=gpu, with_z=with_z and not indexed)
+    if a_shared:
+        host["A"] = host["A"][:, :1].expand(Dm, N).contiguous()
+        d["A"] = host["A"].to(gpu)
     g = torch.Generator().manual_seed(seed + 1)
     K = hip_ops.SCAN_CKPT_EVERY
     ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_()
@@ -264,14 +270,15 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
         operm = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
         kw = dict(z_row_index=zperm.to(gpu), out_row_index=operm.to(gpu), batch_per_dir=Bsz)
         zdev = zsrc.to(gpu)
-        dout = torch.randn(Bsz, L, Dm, generator=g).to(dtype)   # gradient of the MERGED output (token order)
+        # gradient of the MERGED output (token order), or one gradient per direction (token order as well)
+        dout = torch.randn(S if dout_per_seq else Bsz, L, Dm, generator=g).to(dtype)
     else:
         zdev = d["z"]
         dout = torch.randn(S, L, Dm, generator=g).to(dtype)
     out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], True,
-                           ckpt=ckpt, ckpt_every=K, **kw)
+                           ckpt=ckpt, ckpt_every=K, a_shared=a_shared, **kw)
     res = hip_ops.scan_bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], dout.to(gpu), ckpt,
-                           True, ckpt_every=K, **kw)
+                           True, ckpt_every=K, a_shared=a_shared, dout_per_seq=dout_per_seq, **kw)
     torch.cuda.synchronize()
     du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
 
@@ -285,17 +292,32 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
         zs = torch.cat([z[:, zperm[k].long(), :] for k in range(ndir)], 0)        # [S, L, Dm] gathered
         y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=cm(zs), delta_bias=bias, delta_softplus=True))
         # scatter: merged[b, operm[k][l]] += y[k*Bsz+b, l]
-        merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
-        for k in range(ndir):
-            merged = merged.index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
-        loss = (merged * dout.float().double()).sum()
+        if dout_per_seq:                   # direction k's step l lands in row operm[k][l] of ITS OWN token-order slab
+            loss = 0
+            for k in range(ndir):
+                slab = torch.zeros(Bsz, L, Dm, dtype=torch.float64).index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
+                loss = loss + (slab * dout[k * Bsz:(k + 1) * Bsz].float().double()).sum()
+        else:
+            merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+            for k in range(ndir):
+                merged = merged.index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
+            loss = (merged * dout.float().double()).sum()
     else:
         z = leaf(host["z"]) if with_z else None
         y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=None if z is None else cm(z), delta_bias=bias,
                                   delta_softplus=True))
         loss = (y * dout.float().double()).sum()
     loss.backward()
-    rtol, atol = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (4e-2, 6e-2)}[dtype]
+    rtol, atol = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (4e-2, 6e-2), torch.float16: (5e-3, 8e-3)}[dtype]
+    # the forward of the same launch (gated output) against the oracle too
+    rf, af = TOL[dtype]
+    yref = y.detach()
+    if indexed:
+        for k in range(S // Bsz):
+            got = out.float().cpu().double()[k * Bsz:(k + 1) * Bsz][:, operm[k].long()]
+            torch.testing.assert_close(got, yref[k * Bsz:(k + 1) * Bsz], rtol=rf, atol=af * max(1.0, yref.abs().max().item()))
+    else:
+        torch.testing.assert_close(out.float().cpu().double(), yref, rtol=rf, atol=af * max(1.0, yref.abs().max().item()))
 
     def chk(got, ref, name, sum_scale=1.0):
         sc = max(1.0, ref.abs().max().item())
@@ -308,8 +330,10 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
         chk(dz.view(S // Bsz, Bsz, L, Dm).sum(0), z.grad, "dz")
     elif with_z:
         chk(dz, z.grad, "dz")
-    chk(dB, Bm.grad, "dB", 4.0)
-    chk(dC, Cm.grad, "dC", 4.0)
+    # dB / dC are sums over Dm channels, dA / dD / dbias over S*L steps: the absolute floor scales with the root of the count
+    wide = max(1.0, (Dm / 128.0) ** 0.5) if dtype != torch.float32 else 1.0
+    chk(dB, Bm.grad, "dB", 4.0 * wide)
+    chk(dC, Cm.grad, "dC", 4.0 * wide)
     chk(dA, A.grad, "dA", 4.0)
     chk(dD, Dp.grad, "dD", 4.0)
     chk(dbias, bias.grad, "dbias", 4.0)
@@ -330,6 +354,42 @@ def test_scan_bwd_bf16(gpu):
 
 def test_scan_bwd_indexed_three_directions(gpu):
     _scan_bwd_case(gpu, torch.float32, 6, 37, 128, 16, seed=21, indexed=True, Bsz=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("L", [196, 49])
+def test_scan_bwd_bench_instantiation(gpu, dtype, L):
+    """The instantiation bench.py times: D = 1024 (4 waves x 4 workgroups per sequence, the bf16 path
+    sums dB/dC on the matrix pipe), 3 directions through row-index tables sharing z and the merged dout, checkpoints in the
+    dtype's own format -- backward AND forward of that launch against fp64 autograd of the oracle."""
+    _scan_bwd_case(gpu, dtype, 6, L, 1024, 16, seed=100 + L, indexed=True, Bsz=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_scan_bwd_16bit_plain(gpu, dtype):
+    _scan_bwd_case(gpu, dtype, 2, 40, 128, 16, seed=4)
+    _scan_bwd_case(gpu, dtype, 3, 29, 200, 16, seed=5, with_z=False)          # ragged channel count, no gate
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_bwd_a_shared_dout_per_seq(gpu, dtype):
+    """DM_FLAG_A_SHARED + DM_FLAG_DOUT_PER_SEQ at kernel level: the Mamba-2 call pattern of _SpiralSSDFn (one decay per
+    channel, per-direction gradients read through the scatter table)."""
+    _scan_bwd_case(gpu, dtype, 6, 49, 256, 16, seed=31, indexed=True, Bsz=2, a_shared=True, dout_per_seq=True)
+    _scan_bwd_case(gpu, dtype, 3, 196, 1024, 16, seed=32, indexed=True, Bsz=1, a_shared=True, dout_per_seq=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_bwd_dout_per_seq_without_a_shared(gpu, dtype):
+    _scan_bwd_case(gpu, dtype, 4, 37, 128, 16, seed=33, indexed=True, Bsz=2, dout_per_seq=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N", [8, 32])
+def test_scan_bwd_other_dstate(gpu, dtype, N):
+    """The d_state 8 and 32 instantiations of the backward (scan_bwd_impl.h: 32 runs two lanes per channel)."""
+    _scan_bwd_case(gpu, dtype, 2, 21, 128, N, seed=N)
+    _scan_bwd_case(gpu, dtype, 4, 40, 200, N, seed=N + 1, indexed=True, Bsz=2)
 
 
 @pytest.mark.parametrize("Bsz,L,Dm,W", [(2, 196, 256, 4), (2, 30, 128, 4), (1, 5, 200, 3), (1, 1, 64, 4)])

@@ -5,6 +5,8 @@ Run here only (needs /root/reference; the GPU box never sees it):   python tools
 What is captured: everything AROUND the third-party operator comes from the
 reference's own code; the operator itself (mamba_inner_fn, absent wheel mamba-ssm==2.0.4) is stubbed
 with the oracle restatement, so G5 pins the block/model wiring, not the operator arithmetic.
+The OPERATOR arithmetic is pinned by G10: the reference's own pure-PyTorch Mamba.step() / Mamba2.step()
+recurrences (block/mamba.py:405-448, block/mamba2.py:715-775) run token by token.
 No reference source is copied: the fixtures are inputs and outputs only.
 """
 import hashlib
@@ -133,10 +135,151 @@ def main():
             print("G9", bt, "params", sum(p.numel() for p in net.parameters()), "out abs mean", float(out.abs().mean()))
         np.savez_compressed(os.path.join(OUT, "g9_baseline_blocks.npz"), **g)
 
-    if "--only-g9" in sys.argv:
-        g9()
+    # ---- G10 the operator arithmetic the REFERENCE ITSELF holds: Mamba.step() / Mamba2.step() ---------------------------
+    # block/mamba.py:405-448 and block/mamba2.py:715-775 are pure-PyTorch single-token recurrences (conv step, x_proj, dt_proj,
+    # softplus, exp(dt*A) state update, C.h, D skip, SiLU(z) gate, out_proj), reached when `causal_conv1d_update` and
+    # `selective_state_update` are None -- which is what the stubs above install.  Run token by token from zero states in fp64,
+    # the stacked outputs are what mamba_inner_fn / mamba_split_conv1d_scan_combined must produce on the whole sequence: this
+    # pins the oracle's OPERATOR arithmetic to reference-held code (no oracle function is involved in producing G10).
+    def g10():
+        from block.mamba import Mamba as RefMamba
+        from block.mamba2 import Mamba2 as RefMamba2
+        g = {}
+        gen = torch.Generator().manual_seed(1010)
+        rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64)
+        for tag, dm, L in (("m1.a", 32, 16), ("m1.b", 64, 49), ("m1.c", 32, 196)):
+            torch.manual_seed(10 + L)
+            m = RefMamba(d_model=dm, d_state=16, d_conv=4, expand=2).double()
+            with torch.no_grad():
+                dt = torch.exp(torch.rand(m.d_inner, generator=gen, dtype=torch.float64) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+                m.dt_proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+                m.A_log.add_(rnd(*m.A_log.shape) * 0.2)
+                m.A_log.copy_(m.A_log.float().double())        # step() rounds A_log to fp32 (block/mamba.py:431): keep it exact
+                m.D.add_(rnd(*m.D.shape) * 0.3)
+                m.conv1d.bias.add_(rnd(*m.conv1d.bias.shape) * 0.1)
+            Bsz = 2
+            hidden = rnd(Bsz, L, dm)
+            conv_state = torch.zeros(Bsz, m.d_inner, m.d_conv, dtype=torch.float64)
+            ssm_state = torch.zeros(Bsz, m.d_inner, m.d_state, dtype=torch.float64)
+            outs = []
+            with torch.no_grad():
+                for l in range(L):
+                    o, conv_state, ssm_state = m.step(hidden[:, l:l + 1], conv_state, ssm_state)
+                    outs.append(o)
+            out = torch.cat(outs, dim=1)
+            g.update({f"{tag}.sd.{k}": v.numpy() for k, v in m.state_dict().items()})
+            g.update({f"{tag}.hidden": hidden.numpy(), f"{tag}.out": out.numpy(), f"{tag}.last_state": ssm_state.numpy(),
+                      f"{tag}.A": (-torch.exp(m.A_log.detach().float())).numpy()})
+            print("G10", tag, "out abs mean", float(out.abs().mean()))
+        # Mamba-2: rmsnorm=False is held by the reference end to end (gate = y * silu(z), block/mamba2.py:758-759); with
+        # rmsnorm=True the reference calls the absent wheel's RMSNormGated (block/mamba2.py:771), here given the documented
+        # forward of that class for norm_before_gate=False: rmsnorm(y * silu(z)) * weight -- conv, recurrence and D skip are
+        # still the reference's own lines.
+        import mamba_ssm.ops.triton.layernorm_gated as lg
+
+        def _norm_forward(self, x, z=None):
+            x = x * torch.nn.functional.silu(z)
+            return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps) * self.weight
+        lg.RMSNorm.forward = _norm_forward
+        for tag, dm, L, hd, rms in (("m2.a", 32, 16, 16, False), ("m2.b", 64, 49, 64, False), ("m2.c", 64, 196, 32, True),
+                                    ("m2.d", 32, 49, 16, True)):
+            torch.manual_seed(20 + L)
+            m = RefMamba2(d_model=dm, d_state=16, d_conv=4, expand=2, headdim=hd, rmsnorm=rms).double()
+            with torch.no_grad():
+                m.A_log.copy_(m.A_log.float().double())
+                m.D.add_(rnd(*m.D.shape) * 0.3)
+                m.conv1d.bias.add_(rnd(*m.conv1d.bias.shape) * 0.1)
+                if rms:
+                    m.norm.weight.add_(rnd(*m.norm.weight.shape) * 0.2)
+            Bsz = 2
+            hidden = rnd(Bsz, L, dm)
+            conv_dim = m.d_ssm + 2 * m.ngroups * m.d_state
+            conv_state = torch.zeros(Bsz, conv_dim, m.d_conv, dtype=torch.float64)
+            ssm_state = torch.zeros(Bsz, m.nheads, m.headdim, m.d_state, dtype=torch.float64)
+            outs = []
+            with torch.no_grad():
+                for l in range(L):
+                    o, conv_state, ssm_state = m.step(hidden[:, l:l + 1], conv_state, ssm_state)
+                    outs.append(o)
+            out = torch.cat(outs, dim=1)
+            g.update({f"{tag}.sd.{k}": v.numpy() for k, v in m.state_dict().items()})
+            g.update({f"{tag}.hidden": hidden.numpy(), f"{tag}.out": out.numpy(), f"{tag}.headdim": np.asarray(hd),
+                      f"{tag}.rmsnorm": np.asarray(int(rms)), f"{tag}.A": (-torch.exp(m.A_log.detach().float())).numpy()})
+            print("G10", tag, "out abs mean", float(out.abs().mean()))
+        np.savez_compressed(os.path.join(OUT, "g10_reference_step.npz"), **g)
+
+    # ---- G8b CT_Encoder with the reference's SHIPPED weights (pretrain_ct_vision_embedder/*.pt, loaded the way train.py:166-168
+    #      does: the "ema" entry) on a seeded latent; the 9 tensors travel in the fixture (they are data, 263 KB per file) -------
+    def g8b():
+        from block.CT_encoder import CT_Encoder as RefCT
+        g = {}
+        for name in ("brain", "pelvis"):
+            ck = torch.load(os.path.join(REF, "pretrain_ct_vision_embedder", f"{name}_patch_size_2.pt"), map_location="cpu", weights_only=False)
+            for which in ("ema",):
+                sd = ck[which]
+                ct = RefCT(img_size=28, patch_size=2, in_channels=4, embed_dim=512, contain_mask_token=True).eval()
+                ct.load_state_dict(sd)                                  # strict, like train.py:168
+                xin = torch.randn(2, 4, 28, 28, generator=torch.Generator().manual_seed(88)) * 0.18215 * 5
+                with torch.no_grad():
+                    wgt, y2o = ct(xin)
+                tag = f"{name}.{which}"
+                g.update({f"{tag}.sd.{k}": v.numpy() for k, v in sd.items()})
+                g.update({f"{tag}.x": xin.numpy(), f"{tag}.w": wgt.numpy(), f"{tag}.y2": y2o.numpy()})
+                print("G8b", tag, "w range", float(wgt.min()), float(wgt.max()), "y2 abs mean", float(y2o.abs().mean()))
+        np.savez_compressed(os.path.join(OUT, "g8b_ct_encoder_pretrained.npz"), **g)
+
+    # ---- G11 one optimisation step of the reference's training loop on the G5 tiny model:
+    #      loss = training_losses(...)["loss"].mean(); backward; AdamW(lr 1e-4, wd 0).step(); update_ema(ema, model) with the
+    #      reference's own update_ema (train.py:33-43; train.py itself cannot be imported -- torchvision/diffusers/omegaconf are
+    #      absent -- so that one function is compiled from its source text here, in the build container, and run; nothing of it is
+    #      written to the repo), after the initial update_ema(ema, model, decay=0) copy of train.py:201. ---------------------------
+    def g11():
+        import ast
+        from collections import OrderedDict
+        from copy import deepcopy
+        src = open(os.path.join(REF, "train.py")).read()
+        fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "update_ema"][0]
+        ns = {"torch": torch, "OrderedDict": OrderedDict}
+        exec(compile(ast.Module(body=[fn], type_ignores=[]), "reference_train_update_ema", "exec"), ns)
+        ref_update_ema = ns["update_ema"]
+        g5 = np.load(os.path.join(OUT, "g5_tiny_diffma.npz"))
+        net = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16)
+        net.load_state_dict({k[3:]: torch.from_numpy(g5[k]) for k in g5.files if k.startswith("sd.")})
+        net.train()
+        ema = deepcopy(net)
+        for p_ in ema.parameters():
+            p_.requires_grad_(False)
+        ref_update_ema(ema, net, decay=0)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0)
+        d = create_diffusion("")
+        z, nz, tt = (torch.from_numpy(g5[k]) for k in ("loss_z", "loss_noise", "loss_t"))
+        kw = {k: torch.from_numpy(g5[k]) for k in ("y", "y2", "w")}
+        g = {}
+        for step in range(2):
+            loss = d.training_losses(net, z, tt, kw, noise=nz)["loss"].mean()
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            ref_update_ema(ema, net)
+            g[f"step{step}.loss"] = np.asarray(float(loss.detach()))
+            if step == 0:
+                g.update({f"step0.grad.{k}": p_.grad.numpy().copy() for k, p_ in net.named_parameters() if p_.grad is not None and
+                          (k.startswith("blocks.1.mamba1.") or not k.startswith("blocks."))})
+            sel = lambda k: step == 0 or k.startswith("blocks.1.mamba1.") or not k.startswith("blocks.")     # step 1: a subset
+            g.update({f"step{step}.model.{k}": v.detach().numpy().copy() for k, v in net.named_parameters() if v.requires_grad and sel(k)})
+            g.update({f"step{step}.ema.{k}": v.detach().numpy().copy() for k, v in ema.named_parameters()
+                      if net.get_parameter(k).requires_grad and (k.startswith("blocks.1.mamba1.") or not k.startswith("blocks."))})
+            print("G11 step", step, "loss", float(loss.detach()))
+        np.savez_compressed(os.path.join(OUT, "g11_train_step.npz"), **g)
+
+    only = [a for a in sys.argv[1:] if a.startswith("--only-")]
+    if only:
+        for a in only:
+            {"--only-g9": g9, "--only-g10": g10, "--only-g8b": g8b, "--only-g11": g11}[a]()
         return
     g9()
+    g10()
+    g8b()
 
     # ---- G1 spiral -------------------------------------------------------------------------------------
     g1 = {}
@@ -301,6 +444,7 @@ def main():
     out = mamba_ref.mamba_inner_ref(xz, P["cw"], P["cb"], P["xw"], P["dw"], P["ow"], None, P["A"], None, None, P["D"],
                                     delta_bias=P["bias"], delta_softplus=True)
     np.savez_compressed(os.path.join(OUT, "g6_oracle_operator.npz"), xz=xz.numpy(), out=out.numpy(), **{k: v.numpy() for k, v in P.items()})
+    g11()
     print("wrote", sorted(os.listdir(OUT)))
 
 
