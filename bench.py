@@ -57,6 +57,13 @@ def parse():
     return ap.parse_args()
 
 
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def rerandomize_zero_init(model, gen_seed):
     """reference init, then the zero-initialised tensors get N(0, 0.02^2) so that the
     network is not the identity."""
@@ -119,16 +126,39 @@ def cpu_baseline(args, tokens):
     DiffMa-S/7 (BASELINE config 1)."""
     import statistics
 
-    threads = os.cpu_count() or 1
+    ncpu, quota = os.cpu_count() or 1, cgroup_cpu_quota()
+    threads = max(1, min(ncpu, len(os.sched_getaffinity(0)), quota or ncpu))
     n = max(5, args.cpu_steps)
-    main_t = _cpu_train_steps(args.model, n, threads)
     s7_t = _cpu_train_steps("DiffMa-S/7", n, threads)
+    _log(f"cpu_baseline: DiffMa-S/7 at {threads} threads: median {statistics.median(s7_t):.3f} s/step")
+    main_t = _cpu_train_steps(args.model, n, threads)
+    _log(f"cpu_baseline: {args.model} at {threads} threads: median {statistics.median(main_t):.2f} s/step")
     med, med7 = statistics.median(main_t), statistics.median(s7_t)
-    return {"value": 1.0 / med, "unit": "samples*steps/s", "cores": threads, "kind": "port",
+    return {"value": 1.0 / med, "unit": "samples*steps/s", "cores": threads, "kind": "port", "os_cpu_count": ncpu, "cgroup_cpu_quota": quota,
             "sample": f"median of {n} training steps (fwd+bwd+AdamW) after 1 warm-up step, {args.model} at batch 1, fp32, pure-PyTorch "
-                      f"oracle (sequential scan), {threads} threads = os.cpu_count(); {sum(main_t):.1f} s of timed CPU work",
+                      f"oracle (sequential scan), torch.set_num_threads({threads}) = the host cores this container may use "
+                      f"(os.cpu_count() {ncpu}, cgroup cpu.max quota {quota}); {sum(main_t):.1f} s of timed CPU work",
             "step_seconds": [round(x, 3) for x in main_t],
             "s7": {"model": "DiffMa-S/7", "value": 1.0 / med7, "unit": "samples*steps/s", "step_seconds": [round(x, 4) for x in s7_t]}}
+
+
+def cgroup_cpu_quota():
+    """CPUs this container may actually use (cgroup v2 cpu.max or v1 cfs quota); None when unlimited.  The GPU boxes show 256
+    logical CPUs with a quota of 16: 256 threads on 16 CPUs' worth of time is ~100x slower than 16 threads."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(int(q) / int(per)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // per)
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def scan_microbench(dev, nseq=768, L=196, Dm=1024, N=16, iters=20):
@@ -408,13 +438,16 @@ def main():
                                    "opt-in two-stream mode DIFFMA_OVERLAP_MIXERS=1 lets launches of the two mixers share the GPU)"},
             "kernels": kernels,
         }
+        _log(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms/step")
         res["config"]["world_size_seen_by_rccl"] = dist.get_world_size() if dist.is_initialized() else 1
         if not args.no_extras:
             if args.mode == "train" and world == 1 and not args.graph:      # extra steps on one rank only: never with peers waiting in an all-reduce
                 res["gemm"] = gemm_accounting(step, 1e3 * elapsed / args.steps)
+                _log("gemm accounting done")
             if world == 1:
                 torch.cuda.empty_cache()
                 res["selective_scan_fn"] = scan_microbench(dev)
+                _log("scan micro-benchmark done")
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":
             res["cpu_baseline"] = cpu_baseline(args, tokens)
     # RCCL writes its banner / warnings through C stdio (block-buffered on a pipe, NCCL_DEBUG=VERSION is set on the GPU boxes):

@@ -35,6 +35,9 @@ def enable_tuned_gemms(results_file: str | None = None, tune_missing: bool = Tru
         # DIFFMA_TUNE_MS: time budget per candidate solution (default 20 ms; 100+ gives a steadier ranking);
         # DIFFMA_TUNE_FRESH=1: ignore the recorded table and re-time every shape (tools/tune_gemm.sh --fresh)
         tunable.set_max_tuning_duration(int(os.environ.get("DIFFMA_TUNE_MS", "20")))
+        if os.environ.get("DIFFMA_TUNE_NUMCHECK", "1") == "1":
+            # a candidate whose result differs from the default solution's is rejected (16-bit GEMMs differ in summation order only)
+            tunable.set_numerical_check_tolerances(True, 2e-2, 2e-2)
         import tempfile
         tunable.set_filename(write_file or os.path.join(tempfile.gettempdir(), f"diffma_gemm_tuning_{os.getpid()}.csv"), False)
     else:

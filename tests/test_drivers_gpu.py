@@ -257,3 +257,14 @@ def test_train_step_adamw_ema_matches_reference_on_device(gpu):
             elif f.startswith(f"step{step}.ema."):
                 k = f[len(f"step{step}.ema."):]
                 torch.testing.assert_close(ema.get_parameter(k).detach().cpu(), torch.from_numpy(g[f]), rtol=0, atol=3e-7, msg=lambda m, k=k: f"ema {k}: {m}")
+
+
+@pytest.fixture(autouse=True)
+def _isolate_process_wide_gemm_tuning():
+    """train.main / sample.main switch PyTorch's TunableOp on for the whole process (recorded table + online tuning of unseen
+    shapes).  Tests that run later in the same process must not inherit online tuning: restore the library defaults."""
+    yield
+    if torch.cuda.is_available():
+        import torch.cuda.tunable as tunable
+        tunable.tuning_enable(False)
+        tunable.enable(False)
