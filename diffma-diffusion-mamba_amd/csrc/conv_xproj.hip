@@ -1,0 +1,238 @@
+// K3x  dm_gather_conv1d_xproj_fwd -- token gather + causal depthwise conv1d + bias + SiLU + x_proj in ONE pass.
+//
+// BASELINE.json's north star names this kernel ("fused causal depthwise conv1d + SiLU + x-proj").  It replaces, inside
+// mamba_inner_fn (reference call sites block/mamba.py:346-348; mathematics SURVEY.md A.1 steps 2-3):
+//     CrossScan gather  ->  causal_conv1d_fwd + SiLU  ->  x_dbl = x~ @ x_proj.weight^T
+// The unfused path writes x~ ([ndir*B, L, D]) and the library GEMM reads all of it back for a skinny (D -> R + 2N = 64)
+// product; here the 16-row x~ tile a workgroup has just produced goes to LDS as 16-bit MFMA A-fragments and the product
+// rides on the otherwise idle matrix pipe of an HBM-bound kernel.
+//
+// Mapping (CDNA4): one 256-thread workgroup (4 waves) walks ONE gathered sequence from l = 0 to L-1 in tiles of 16 rows.
+//   conv phase : thread t owns channels {512*cb + 2t, +1} (32-bit accesses); the (W-1)-row window slides through registers
+//                from tile to tile, so every x row is loaded exactly once per direction (no halo re-reads);
+//   x_proj     : wave w owns output columns 16w .. 16w+15; its x_proj.weight rows live in registers as MFMA B-fragments for
+//                the whole sequence (KSTEPS * 4 VGPRs), the A-fragments are ds_read_b128 from the padded LDS tile,
+//                v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulation, one 16 x 16 output tile per wave and row tile.
+// Two LDS tile buffers alternate, so there is one barrier per tile.  Algorithmic bytes: 2*s per element and direction (read
+// x, write x~) + the x_dbl rows.
+#include <type_traits>
+#include "dm_common.h"
+
+namespace dm {
+
+constexpr int XP_TM = 16;                 // rows per tile (MFMA M)
+constexpr int XP_THREADS = 256;
+constexpr int XP_CB = 2 * XP_THREADS;     // channels per conv pass (2 per thread)
+constexpr int XP_PAD = 8;                 // tile row padding in elements (16 B): spreads the 16 rows of an A-fragment read over the banks
+
+typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 xp_f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t xp_u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct xp_mfma;
+template <> struct xp_mfma<bf16_t> {
+    static __device__ __forceinline__ f32x4 run(const xp_u32x4& a, const xp_u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(xp_bf16x8, a), __builtin_bit_cast(xp_bf16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        uint32_t r;
+        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        return r;
+    }
+    static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+        lo = __uint_as_float(w << 16);
+        hi = __uint_as_float(w & 0xffff0000u);
+    }
+};
+template <> struct xp_mfma<f16_t> {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x4 run(const xp_u32x4& a, const xp_u32x4& b, const f32x4& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(xp_f16x8, a), __builtin_bit_cast(xp_f16x8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
+        h2 v;
+        v.x = (_Float16)lo;
+        v.y = (_Float16)hi;
+        return __builtin_bit_cast(uint32_t, v);
+    }
+    static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {
+        const h2 v = __builtin_bit_cast(h2, w);
+        lo = (float)v.x;
+        hi = (float)v.y;
+    }
+};
+
+// KSTEPS = dim / 32 (MFMA K steps); NCB = ceil(dim / 512) conv passes per thread.
+template <typename T, typename TW, int W, bool SILU, int KSTEPS>
+__global__ __launch_bounds__(XP_THREADS) void conv_xproj_fwd_kernel(const dm_conv_xproj_fwd_args p) {
+    constexpr int D = KSTEPS * 32;
+    constexpr int NCB = (D + XP_CB - 1) / XP_CB;
+    constexpr int ROW = D + XP_PAD;                                  // LDS row stride in elements
+    __shared__ __attribute__((aligned(16))) uint16_t tile[2][XP_TM * ROW];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g = lane >> 4, ij = lane & 15;
+    const int s = blockIdx.x;                                        // dir * batch + b
+    const int dir = s / p.batch;
+    const int b = s - dir * p.batch;
+    const int L = p.seqlen;
+    const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
+    const T* __restrict__ xp = (const T*)p.x + (int64_t)b * p.x_sb;
+    T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss;
+    T* __restrict__ xd = (T*)p.xdbl + (int64_t)s * L * p.xd_sr;
+
+    // ---- x_proj.weight rows of this wave's 16 output columns as B-fragments: lane (g, j) holds Wx[16w + j][32kk + 8g .. +7] ----
+    const int ncol = p.nproj;
+    const int col = wave * 16 + ij;
+    const bool wave_on = wave * 16 < ncol;                           // wave-uniform
+    xp_u32x4 bfrag[KSTEPS];
+#pragma unroll
+    for (int kk = 0; kk < KSTEPS; ++kk) {
+        bfrag[kk] = (xp_u32x4){0u, 0u, 0u, 0u};
+        if (wave_on && col < ncol) bfrag[kk] = *reinterpret_cast<const xp_u32x4*>((const T*)p.wx + (int64_t)col * D + kk * 32 + g * 8);
+    }
+
+    // ---- conv constants and the sliding window of this thread's channels ----
+    float w[NCB][W][2], bias[NCB][2], win[NCB][W - 1][2];
+    bool act[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int c = cb * XP_CB + 2 * tid;
+        act[cb] = c < D;
+        const int cc = act[cb] ? c : 0;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) w[cb][j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(cc + v) * W + j);
+            bias[cb][v] = p.bias ? io<TW>::ld((const TW*)p.bias + cc + v) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < W - 1; ++j) win[cb][j][v] = 0.0f;     // left zero padding
+        }
+    }
+
+    const int ntile = (L + XP_TM - 1) / XP_TM;
+    for (int t = 0; t < ntile; ++t) {
+        const int l0 = t * XP_TM;
+        uint16_t* const tl = tile[t & 1];
+        // all row loads of the tile up front (memory-level parallelism), then the window slides through them
+        uint32_t xin[NCB][XP_TM];
+#pragma unroll
+        for (int j = 0; j < XP_TM; ++j) {
+            int l = l0 + j;
+            l = l < L ? l : L - 1;
+            const int r = idx ? idx[l] : l;
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int c = act[cb] ? cb * XP_CB + 2 * tid : 0;
+                xin[cb][j] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)r * p.x_sl + c);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < XP_TM; ++j) {
+            const bool valid = l0 + j < L;                            // wave-uniform
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) {
+                float xv[2], acc[2];
+                xp_mfma<T>::unpack(xin[cb][j], xv[0], xv[1]);
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    acc[v] = bias[cb][v] + w[cb][W - 1][v] * xv[v];
+#pragma unroll
+                    for (int k = 0; k < W - 1; ++k) acc[v] += w[cb][k][v] * win[cb][k][v];
+                    if (SILU) acc[v] = silu_f(acc[v]);
+#pragma unroll
+                    for (int k = 0; k < W - 2; ++k) win[cb][k][v] = win[cb][k + 1][v];
+                    win[cb][W - 2][v] = xv[v];
+                }
+                const uint32_t pk = valid ? xp_mfma<T>::pack(acc[0], acc[1]) : 0u;
+                if (act[cb]) {
+                    const int c = cb * XP_CB + 2 * tid;
+                    *reinterpret_cast<uint32_t*>(tl + j * ROW + c) = pk;               // the A tile the matrix pipe reads (16-bit, rounded like x~)
+                    if (valid) *reinterpret_cast<uint32_t*>(op + (int64_t)(l0 + j) * p.o_sl + c) = pk;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave_on) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const xp_u32x4 a = *reinterpret_cast<const xp_u32x4*>(tl + ij * ROW + kk * 32 + g * 8);   // A[i = ij][32kk + 8g .. +7]
+                acc = xp_mfma<T>::run(a, bfrag[kk], acc);
+            }
+            if (col < ncol) {                                          // D[4g + r][j]: rows l0 + 4g + r of column 16w + j
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int l = l0 + 4 * g + r;
+                    if (l < L) io<T>::st(xd + (int64_t)l * p.xd_sr + col, acc[r]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T, typename TW, int W, int KSTEPS>
+static void launch_xp(const dm_conv_xproj_fwd_args& a, hipStream_t st) {
+    dim3 grid(a.ndir * a.batch), block(XP_THREADS);
+    if (a.flags & DM_FLAG_SILU) hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, true, KSTEPS>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, false, KSTEPS>), grid, block, 0, st, a);
+}
+
+template <typename T, typename TW, int W>
+static int xp_by_dim(const dm_conv_xproj_fwd_args& a, hipStream_t st) {
+    switch (a.dim) {
+        case 1024: launch_xp<T, TW, W, 32>(a, st); break;
+#ifndef DM_FAST_BUILD
+        case 512: launch_xp<T, TW, W, 16>(a, st); break;
+        case 256: launch_xp<T, TW, W, 8>(a, st); break;
+#endif
+        case 128: launch_xp<T, TW, W, 4>(a, st); break;
+        default: set_error("dm_gather_conv1d_xproj_fwd: dim %d not instantiated (128, 256, 512, 1024)", a.dim); return DM_ERR_ARG;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_gather_conv1d_xproj_fwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+
+template <typename T, typename TW>
+static int xp_by_width(const dm_conv_xproj_fwd_args& a, hipStream_t st) {
+    switch (a.width) {
+        case 4: return xp_by_dim<T, TW, 4>(a, st);
+#ifndef DM_FAST_BUILD
+        case 3: return xp_by_dim<T, TW, 3>(a, st);
+        case 2: return xp_by_dim<T, TW, 2>(a, st);
+#endif
+        default: set_error("dm_gather_conv1d_xproj_fwd: width %d not in {2,3,4}", a.width); return DM_ERR_ARG;
+    }
+}
+
+}  // namespace dm
+
+extern "C" int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype) {
+    const bool d_ok = dim == 128 || dim == 256 || dim == 512 || dim == 1024;
+    return (d_ok && nproj >= 1 && nproj <= 64 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;
+}
+
+extern "C" int dm_gather_conv1d_xproj_fwd(const dm_conv_xproj_fwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_gather_conv1d_xproj_fwd: null args"); return DM_ERR_ARG; }
+    const dm_conv_xproj_fwd_args& a = *args;
+    if (!a.x || !a.weight || !a.out || !a.wx || !a.xdbl) { set_error("dm_gather_conv1d_xproj_fwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_xproj_fwd: non-positive size"); return DM_ERR_ARG; }
+    if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_xproj_fwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
+    if (!dm_gather_conv1d_xproj_supported(a.dim, a.nproj, a.io_dtype)) {
+        set_error("dm_gather_conv1d_xproj_fwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj <= 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
+        return DM_ERR_ARG;
+    }
+    if (a.x_sd != 1 || a.o_sd != 1) { set_error("dm_gather_conv1d_xproj_fwd: needs token-major tensors (channel stride 1)"); return DM_ERR_LAYOUT; }
+    if (((uintptr_t)a.x & 3) || (a.x_sb & 1) || (a.x_sl & 1) || ((uintptr_t)a.out & 3) || (a.o_ss & 1) || (a.o_sl & 1) || ((uintptr_t)a.wx & 15)) {
+        set_error("dm_gather_conv1d_xproj_fwd: x / out need 4-byte aligned rows, wx a 16-byte aligned base");
+        return DM_ERR_LAYOUT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const bool wf32 = a.w_dtype == DM_F32;
+    if (!wf32 && a.w_dtype != a.io_dtype) { set_error("dm_gather_conv1d_xproj_fwd: w_dtype must be fp32 or io_dtype"); return DM_ERR_DTYPE; }
+    if (a.io_dtype == DM_BF16) return wf32 ? xp_by_width<bf16_t, float>(a, st) : xp_by_width<bf16_t, bf16_t>(a, st);
+    return wf32 ? xp_by_width<f16_t, float>(a, st) : xp_by_width<f16_t, f16_t>(a, st);
+}

@@ -24,6 +24,9 @@
 namespace dm {
 
 constexpr int FWD_CKE = 4;     // steps between checkpoints (the backward's sub-chunk length)
+#ifndef DM_FWD_F32_WAVES
+#define DM_FWD_F32_WAVES 1     // minimum waves per SIMD requested for the fp32-I/O instantiations (register budget 512 / waves)
+#endif
 
 // One time step of the recurrence for one lane.
 // ASH (DM_FLAG_A_SHARED): every state of the channel decays with the same factor -> one exp per step.
@@ -62,7 +65,7 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 // IDX : z_row_index / out_row_index tables are used (both non-null)
 // CKPT: the state is written to p.ckpt after every FWD_CKE = 4 steps (fp32, or bf16 pairs for bf16 I/O)
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF, bool ASH = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : 1))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : ((sizeof(T) == 4 && N <= 16) ? DM_FWD_F32_WAVES : 1)))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
     static_assert(N % 2 == 0, "d_state must be even");
     static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
     constexpr int NP = N / 2;

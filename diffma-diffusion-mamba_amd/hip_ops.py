@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -290,6 +290,51 @@ def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out
     a.o_ss, a.o_sl, a.o_sd = out.stride()
     _launch("dm_gather_conv1d_fwd", a, x, 2 * ndir * Bsz * L * Dm * x.element_size())
     return out
+
+
+# Fused conv + x_proj (csrc/conv_xproj.hip): one workgroup walks one gathered sequence, so a launch needs at least a few
+# sequences per CU to fill the chip; below that the unfused pair (chunk-parallel conv + library GEMM) is used.
+XPROJ_FUSED_MIN_SEQS = 256
+
+
+def conv_xproj_supported(x, wx, nseq):
+    """True when dm_gather_conv1d_xproj_fwd serves this call (16-bit I/O, dim in {128..1024}, <= 64 projection rows)."""
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or nseq < XPROJ_FUSED_MIN_SEQS:
+        return False
+    if x.stride(0) % 2 or x.stride(1) % 2 or x.storage_offset() % 2:
+        return False
+    return bool(_lib.load().dm_gather_conv1d_xproj_supported(int(x.shape[-1]), int(wx.shape[0]), dtype_code(x)))
+
+
+def gather_conv1d_xproj_fwd(x, weight, bias, wx, *, row_index=None, ndir=1, silu=True):
+    """x: [B, L, Dm] token-major view; weight [Dm, W]; wx [P, Dm] (x_proj.weight, same dtype as x).
+    Returns (xc [ndir*B, L, Dm] = SiLU(conv(gathered x)), x_dbl [ndir*B*L, P] = xc @ wx^T) from ONE kernel."""
+    _require_gpu(x, weight, bias, wx)
+    Bsz, L, Dm = x.shape
+    W = weight.shape[-1]
+    P = wx.shape[0]
+    weight = weight.reshape(Dm, W).contiguous()
+    if weight.dtype != x.dtype and weight.dtype != torch.float32:
+        weight = weight.float()
+    if bias is not None:
+        bias = bias.to(weight.dtype).contiguous()
+    wx = wx.contiguous()
+    assert wx.dtype == x.dtype and wx.shape[1] == Dm
+    out = torch.empty((ndir * Bsz, L, Dm), dtype=x.dtype, device=x.device)
+    xdbl = torch.empty((ndir * Bsz * L, P), dtype=x.dtype, device=x.device)
+    a = dm_conv_xproj_fwd_args()
+    a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
+    a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
+    a.flags = DM_FLAG_SILU if silu else 0
+    a.nproj = P
+    a.x, a.weight, a.bias, a.row_index = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index)
+    a.wx, a.out, a.xdbl = _ptr(wx), _ptr(out), _ptr(xdbl)
+    a.x_sb, a.x_sl, a.x_sd = x.stride()
+    a.o_ss, a.o_sl, a.o_sd = out.stride()
+    a.xd_sr = P
+    es = x.element_size()
+    _launch("dm_gather_conv1d_xproj_fwd", a, x, 2 * ndir * Bsz * L * Dm * es + ndir * Bsz * L * P * es + P * Dm * es)
+    return out, xdbl
 
 
 def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=True):

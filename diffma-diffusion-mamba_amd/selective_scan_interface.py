@@ -239,9 +239,13 @@ class _SpiralSSMFn(torch.autograd.Function):
         dt_ = xz.dtype
         x_view, z_view = xz[..., :Din], xz[..., Din:]
         need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
-        xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
         Wx_c, Wdt_c = Wx.to(dt_), Wdt.to(dt_)                                  # kept for the backward (one cast per step, not two)
-        x_dbl = GemmChain.run(F.linear, xc.view(-1, Din), Wx_c)                # [ndir*B*L, R+2N]
+        if hip_ops.conv_xproj_supported(x_view, Wx_c, ndir * Bsz):
+            # gather + conv + SiLU + x_proj in one kernel: x~ is projected while its tile is still on the CU
+            xc, x_dbl = hip_ops.gather_conv1d_xproj_fwd(x_view, conv_w, conv_b, Wx_c, row_index=scan_index, ndir=ndir, silu=True)
+        else:
+            xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
+            x_dbl = GemmChain.run(F.linear, xc.view(-1, Din), Wx_c)            # [ndir*B*L, R+2N]
         delta = GemmChain.run(F.linear, x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]

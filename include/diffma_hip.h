@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 9
+#define DM_ABI_VERSION 10
 
 typedef enum {
     DM_OK = 0,
@@ -198,6 +198,35 @@ typedef struct {
 
 int dm_gather_conv1d_bwd(const dm_conv_bwd_args *args, void *stream);
 int dm_conv_nchunk(int seqlen);
+
+/* ------------------------------------------------------------------------------------------------
+ * The same forward FUSED with x_proj (BASELINE north star: "fused causal depthwise conv1d + SiLU + x-proj kernel"):
+ *   out  = as dm_gather_conv1d_fwd                                  [ndir*batch][seqlen][dim]
+ *   xdbl[(s*seqlen + l)][c] = sum_d out[s][l][d] * wx[c][d]         c < nproj   (x_dbl = x~ @ x_proj.weight^T, block/mamba.py:346,
+ *                                                                    SURVEY.md A.1 step 3; fp32 accumulation on the matrix pipe)
+ * wx: [nproj][dim] in the I/O dtype, contiguous (x_proj.weight as it is), 16-byte aligned.  16-bit I/O only, dim in
+ * {128, 256, 512, 1024}, nproj <= 64: dm_gather_conv1d_xproj_supported() tells; other shapes take the unfused pair.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, dim, seqlen, width, ndir;
+    int32_t io_dtype, w_dtype;
+    int32_t flags;
+    int32_t nproj;            /* rows of wx = columns of xdbl (dt_rank + 2*d_state) */
+    int32_t _pad;
+    const void *x;
+    const void *weight;       /* [dim][width], w_dtype, contiguous */
+    const void *bias;         /* [dim] or NULL, w_dtype            */
+    const int32_t *row_index; /* [ndir][seqlen] or NULL            */
+    const void *wx;           /* [nproj][dim], io_dtype            */
+    void *out;
+    void *xdbl;               /* [ndir*batch*seqlen][*], io_dtype, row stride xd_sr */
+    int64_t x_sb, x_sl, x_sd;
+    int64_t o_ss, o_sl, o_sd;
+    int64_t xd_sr;
+} dm_conv_xproj_fwd_args;
+
+int dm_gather_conv1d_xproj_fwd(const dm_conv_xproj_fwd_args *args, void *stream);
+int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * Token merge: out[b][t][c] = sum_k in[k][b][ idx[k][t] ][c]     (idx NULL = identity).

@@ -232,6 +232,40 @@ def test_gather_conv_fwd_matches_oracle(gpu, dtype, Bsz, L, Dm, W):
         torch.testing.assert_close(out[k].double(), ref, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,P,W,with_idx", [(2, 196, 1024, 64, 4, True), (3, 49, 128, 36, 4, True), (1, 16, 128, 40, 4, False),
+                                                   (2, 37, 256, 64, 3, True), (1, 1, 512, 16, 2, False), (2, 5, 1024, 33, 4, True)])
+def test_fused_conv_xproj_fwd_matches_oracle(gpu, dtype, Bsz, L, Dm, P, W, with_idx):
+    """K3x (csrc/conv_xproj.hip): x~ = SiLU(conv(gathered x)) and x_dbl = x~ @ Wx^T from one kernel vs the fp64 oracle conv and an
+    fp64 product of the ROUNDED x~ (that is what mamba_inner_fn's x_proj sees as well).  Ragged L (partial last tile), projection
+    widths that are not a multiple of 16, all conv widths, with and without the 3-direction gather."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import causal_conv1d_ref
+
+    g = torch.Generator().manual_seed(L * 3 + Dm + P)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g).to(dtype)
+    w = torch.randn(Dm, W, generator=g) * 0.5
+    b = torch.randn(Dm, generator=g) * 0.1
+    wx = (torch.randn(P, Dm, generator=g) * 0.1).to(dtype)
+    ndir = 3 if with_idx else 1
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    xc, xdbl = hip_ops.gather_conv1d_xproj_fwd(xz.to(gpu)[..., :Dm], w.to(gpu), b.to(gpu), wx.to(gpu),
+                                               row_index=perms.to(gpu) if with_idx else None, ndir=ndir)
+    torch.cuda.synchronize()
+    assert xc.shape == (ndir * Bsz, L, Dm) and xdbl.shape == (ndir * Bsz * L, P)
+    xc_c = xc.float().cpu().view(ndir, Bsz, L, Dm)
+    rtol, atol = TOL[dtype]
+    for k in range(ndir):
+        xs = xz[..., :Dm].float()[:, perms[k].long(), :]
+        ref = causal_conv1d_ref(xs.permute(0, 2, 1).double(), w.double(), b.double(), activation="silu").permute(0, 2, 1)
+        torch.testing.assert_close(xc_c[k].double(), ref, rtol=rtol, atol=atol)
+    # bit-identical to the unfused conv kernel, and the projection of those very values in fp64
+    plain = hip_ops.gather_conv1d_fwd(xz.to(gpu)[..., :Dm], w.to(gpu), b.to(gpu), row_index=perms.to(gpu) if with_idx else None, ndir=ndir)
+    assert torch.equal(plain, xc)
+    ref_dbl = xc.float().cpu().double().view(-1, Dm) @ wx.float().double().t()
+    torch.testing.assert_close(xdbl.float().cpu().double(), ref_dbl, rtol=rtol, atol=atol * max(1.0, ref_dbl.abs().max().item()))
+
+
 def test_token_merge_exact(gpu):
     from diffma_amd import hip_ops
 

@@ -631,3 +631,38 @@ def test_mamba_module_matches_reference_step(gpu, tag):
     with torch.no_grad():
         out = mix(hidden.float().to(gpu), "zigma")
     assert rel_l2(out.cpu(), want) <= 1e-4, rel_l2(out.cpu(), want)
+
+
+def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
+    """The fused conv + x_proj kernel (K3x) is selected by launch size; force it on at test sizes and repeat the bf16 mixer
+    forward/backward check against fp64 oracle autograd, the bf16 G5 denoiser, and the bf16/fp16 G10 reference-step parity."""
+    from diffma_amd import hip_ops
+    from diffma_amd.selective_scan_interface import mamba_inner_fn
+
+    calls = {"n": 0}
+    real = hip_ops.gather_conv1d_xproj_fwd
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(hip_ops, "XPROJ_FUSED_MIN_SEQS", 1)
+    monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_fwd", counted)
+    _mixer_case(gpu, torch.bfloat16, 2e-2)
+    assert calls["n"] >= 1
+    g, sd, net, inp = _g5(gpu)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).float().cpu()
+    assert rel_l2(out, torch.from_numpy(g["out"])) <= 2e-2
+    n0 = calls["n"]
+    for tag in ("m1.b", "m1.c"):
+        for dtype, tol in ((torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+            sd10, e = _g10(tag)
+            hidden, want = torch.from_numpy(e["hidden"]), torch.from_numpy(e["out"])
+            f = lambda t: t.float().to(gpu)
+            xz = torch.einsum("ed,bld->bel", sd10["in_proj.weight"], hidden)
+            o = mamba_inner_fn(xz.to(dtype).to(gpu), f(sd10["conv1d.weight"]), f(sd10["conv1d.bias"]), f(sd10["x_proj.weight"]).to(dtype),
+                               f(sd10["dt_proj.weight"]).to(dtype), f(sd10["out_proj.weight"]).to(dtype), None, f(torch.from_numpy(e["A"])),
+                               None, None, f(sd10["D"]), delta_bias=f(sd10["dt_proj.bias"]), delta_softplus=True)
+            assert rel_l2(o.float().cpu(), want) <= tol, (tag, dtype, rel_l2(o.float().cpu(), want))
+    assert calls["n"] > n0
