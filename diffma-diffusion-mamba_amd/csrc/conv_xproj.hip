@@ -21,8 +21,7 @@
 namespace dm {
 
 constexpr int XP_TM = 16;                 // rows per tile (MFMA M)
-constexpr int XP_THREADS = 256;
-constexpr int XP_CB = 2 * XP_THREADS;     // channels per conv pass (2 per thread)
+constexpr int XP_THREADS = 512;           // 8 waves: wave w owns output columns 16*(w&3).. and the K half (w>>2)
 constexpr int XP_PAD = 8;                 // tile row padding in elements (16 B): spreads the 16 rows of an A-fragment read over the banks
 
 typedef __bf16 xp_bf16x8 __attribute__((ext_vector_type(8)));
@@ -62,111 +61,126 @@ template <> struct xp_mfma<f16_t> {
     }
 };
 
-// KSTEPS = dim / 32 (MFMA K steps); NCB = ceil(dim / 512) conv passes per thread.
-template <typename T, typename TW, int W, bool SILU, int KSTEPS>
-__global__ __launch_bounds__(XP_THREADS) void conv_xproj_fwd_kernel(const dm_conv_xproj_fwd_args p) {
+// KSTEPS = dim / 32 (MFMA K steps, even).  Thread t owns channels 2t, 2t+1 (dim <= 1024).
+template <typename T, typename TW, int W, bool SILU, int KSTEPS, bool IDX>
+__global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_fwd_kernel(const dm_conv_xproj_fwd_args p) {
     constexpr int D = KSTEPS * 32;
-    constexpr int NCB = (D + XP_CB - 1) / XP_CB;
+    constexpr int KH = KSTEPS / 2;                                   // K steps per wave
     constexpr int ROW = D + XP_PAD;                                  // LDS row stride in elements
+    static_assert(KSTEPS % 2 == 0 && D <= 2 * XP_THREADS, "dim must be a multiple of 64 and at most 1024");
     __shared__ __attribute__((aligned(16))) uint16_t tile[2][XP_TM * ROW];
+    __shared__ __attribute__((aligned(16))) f32x4 red[4][WAVE];      // partial accumulators of the upper K half
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int nt = wave & 3, kh = wave >> 2;
     const int g = lane >> 4, ij = lane & 15;
     const int s = blockIdx.x;                                        // dir * batch + b
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
-    const int32_t* __restrict__ idx = p.row_index ? p.row_index + (int64_t)dir * L : nullptr;
-    const T* __restrict__ xp = (const T*)p.x + (int64_t)b * p.x_sb;
-    T* __restrict__ op = (T*)p.out + (int64_t)s * p.o_ss;
-    T* __restrict__ xd = (T*)p.xdbl + (int64_t)s * L * p.xd_sr;
+    const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;     // scalar loads
+    const bool act = (D == 2 * XP_THREADS) ? true : (2 * tid < D);     // compile-time true for dim 1024
+    const int c = act ? 2 * tid : 0;
+    // SRD addressing (dm_common.h): the lane's channel offset in one VGPR, the wave-uniform row offset in an SGPR
+    const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)b * p.x_sb);
+    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss);
+    const int vo = c * (int)sizeof(T);
+    const int sl_x = (int)p.x_sl * (int)sizeof(T), sl_o = (int)p.o_sl * (int)sizeof(T);
+    const rsrc_t r_xd = make_rsrc((T*)p.xdbl + (int64_t)s * L * p.xd_sr);
+    const int sr_xd = (int)p.xd_sr * (int)sizeof(T);
 
-    // ---- x_proj.weight rows of this wave's 16 output columns as B-fragments: lane (g, j) holds Wx[16w + j][32kk + 8g .. +7] ----
+    // ---- x_proj.weight rows of this wave's 16 output columns and K half as B-fragments:
+    //      lane (g, j) holds Wx[16 nt + j][32 (kh*KH + kk) + 8g .. +7] ----
     const int ncol = p.nproj;
-    const int col = wave * 16 + ij;
-    const bool wave_on = wave * 16 < ncol;                           // wave-uniform
-    xp_u32x4 bfrag[KSTEPS];
+    const int col = nt * 16 + ij;
+    const bool wave_on = nt * 16 < ncol;                             // wave-uniform
+    xp_u32x4 bfrag[KH];
+    {   // a bounded descriptor: columns >= nproj read as zero, no branches
+        const rsrc_t r_wx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.wx), 0, ncol * D * (int)sizeof(T), 0x00020000);
 #pragma unroll
-    for (int kk = 0; kk < KSTEPS; ++kk) {
-        bfrag[kk] = (xp_u32x4){0u, 0u, 0u, 0u};
-        if (wave_on && col < ncol) bfrag[kk] = *reinterpret_cast<const xp_u32x4*>((const T*)p.wx + (int64_t)col * D + kk * 32 + g * 8);
-    }
-
-    // ---- conv constants and the sliding window of this thread's channels ----
-    float w[NCB][W][2], bias[NCB][2], win[NCB][W - 1][2];
-    bool act[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        const int c = cb * XP_CB + 2 * tid;
-        act[cb] = c < D;
-        const int cc = act[cb] ? c : 0;
-#pragma unroll
-        for (int v = 0; v < 2; ++v) {
-#pragma unroll
-            for (int j = 0; j < W; ++j) w[cb][j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(cc + v) * W + j);
-            bias[cb][v] = p.bias ? io<TW>::ld((const TW*)p.bias + cc + v) : 0.0f;
-#pragma unroll
-            for (int j = 0; j < W - 1; ++j) win[cb][j][v] = 0.0f;     // left zero padding
+        for (int kk = 0; kk < KH; ++kk) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_wx, (col * D + (kh * KH + kk) * 32 + g * 8) * (int)sizeof(T), 0, 0);
+            bfrag[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
         }
     }
 
+    // ---- conv constants and the sliding window of this thread's two channels ----
+    float w[W][2], bias[2], win[W - 1][2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) w[j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(c + v) * W + j);
+        bias[v] = p.bias ? io<TW>::ld((const TW*)p.bias + c + v) : 0.0f;
+#pragma unroll
+        for (int j = 0; j < W - 1; ++j) win[j][v] = 0.0f;             // left zero padding
+    }
+
+    // the 16 row loads of a tile are issued in two halves, each as soon as the registers of the same half of the previous tile
+    // have been consumed: the x rows of tile t+1 are in flight while tile t is convolved, projected and stored
+    auto load_half = [&](int l0, int h, uint32_t(&xin)[XP_TM]) {
+#pragma unroll
+        for (int j = h * (XP_TM / 2); j < (h + 1) * (XP_TM / 2); ++j) {
+            int l = l0 + j;
+            l = l < L ? l : L - 1;
+            const int r = IDX ? idx[l] : l;
+            xin[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo, r * sl_x, 0);
+        }
+    };
     const int ntile = (L + XP_TM - 1) / XP_TM;
+    uint32_t xin[XP_TM];
+    load_half(0, 0, xin);
+    load_half(0, 1, xin);
+    // one half (8 rows) of a tile: convolve, round, park in the LDS tile, store x~, then refill the half's registers from the next tile
+    auto conv_half = [&](int t, int h) {
+        const int l0 = t * XP_TM;
+        uint16_t* const tl = tile[t & 1];
+#pragma unroll
+        for (int j = h * (XP_TM / 2); j < (h + 1) * (XP_TM / 2); ++j) {
+            const bool valid = l0 + j < L;                            // wave-uniform
+            float xv[2], acc[2];
+            xp_mfma<T>::unpack(xin[j], xv[0], xv[1]);
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                acc[v] = bias[v];                                     // same summation order as conv_fwd_kernel: bit-identical x~
+#pragma unroll
+                for (int k = 0; k < W - 1; ++k) acc[v] += w[k][v] * win[k][v];
+                acc[v] += w[W - 1][v] * xv[v];
+                if (SILU) acc[v] = silu_f(acc[v]);
+#pragma unroll
+                for (int k = 0; k < W - 2; ++k) win[k][v] = win[k + 1][v];
+                if (W > 1) win[W - 2][v] = xv[v];
+            }
+            const uint32_t pk = valid ? xp_mfma<T>::pack(acc[0], acc[1]) : 0u;
+            if (act) {
+                *reinterpret_cast<uint32_t*>(tl + j * ROW + c) = pk;               // the A tile the matrix pipe reads (16-bit, rounded like x~)
+                if (valid) __builtin_amdgcn_raw_buffer_store_b32(pk, r_o, vo, (l0 + j) * sl_o, 0);
+            }
+        }
+        if (t + 1 < ntile) load_half(l0 + XP_TM, h, xin);
+    };
     for (int t = 0; t < ntile; ++t) {
         const int l0 = t * XP_TM;
         uint16_t* const tl = tile[t & 1];
-        // all row loads of the tile up front (memory-level parallelism), then the window slides through them
-        uint32_t xin[NCB][XP_TM];
-#pragma unroll
-        for (int j = 0; j < XP_TM; ++j) {
-            int l = l0 + j;
-            l = l < L ? l : L - 1;
-            const int r = idx ? idx[l] : l;
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const int c = act[cb] ? cb * XP_CB + 2 * tid : 0;
-                xin[cb][j] = *reinterpret_cast<const uint32_t*>(xp + (int64_t)r * p.x_sl + c);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < XP_TM; ++j) {
-            const bool valid = l0 + j < L;                            // wave-uniform
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                float xv[2], acc[2];
-                xp_mfma<T>::unpack(xin[cb][j], xv[0], xv[1]);
-#pragma unroll
-                for (int v = 0; v < 2; ++v) {
-                    acc[v] = bias[cb][v] + w[cb][W - 1][v] * xv[v];
-#pragma unroll
-                    for (int k = 0; k < W - 1; ++k) acc[v] += w[cb][k][v] * win[cb][k][v];
-                    if (SILU) acc[v] = silu_f(acc[v]);
-#pragma unroll
-                    for (int k = 0; k < W - 2; ++k) win[cb][k][v] = win[cb][k + 1][v];
-                    win[cb][W - 2][v] = xv[v];
-                }
-                const uint32_t pk = valid ? xp_mfma<T>::pack(acc[0], acc[1]) : 0u;
-                if (act[cb]) {
-                    const int c = cb * XP_CB + 2 * tid;
-                    *reinterpret_cast<uint32_t*>(tl + j * ROW + c) = pk;               // the A tile the matrix pipe reads (16-bit, rounded like x~)
-                    if (valid) *reinterpret_cast<uint32_t*>(op + (int64_t)(l0 + j) * p.o_sl + c) = pk;
-                }
-            }
-        }
+        conv_half(t, 0);
+        conv_half(t, 1);
         __syncthreads();
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         if (wave_on) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                const xp_u32x4 a = *reinterpret_cast<const xp_u32x4*>(tl + ij * ROW + kk * 32 + g * 8);   // A[i = ij][32kk + 8g .. +7]
+            for (int kk = 0; kk < KH; ++kk) {
+                const xp_u32x4 a = *reinterpret_cast<const xp_u32x4*>(tl + ij * ROW + (kh * KH + kk) * 32 + g * 8);   // A[i = ij][k .. k+7]
                 acc = xp_mfma<T>::run(a, bfrag[kk], acc);
             }
-            if (col < ncol) {                                          // D[4g + r][j]: rows l0 + 4g + r of column 16w + j
+            if (kh == 1) red[nt][lane] = acc;
+        }
+        __syncthreads();
+        if (wave_on && kh == 0 && col < ncol) {                        // D[4g + r][j]: rows l0 + 4g + r of column 16 nt + j
+            const f32x4 o = acc + red[nt][lane];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int l = l0 + 4 * g + r;
-                    if (l < L) io<T>::st(xd + (int64_t)l * p.xd_sr + col, acc[r]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int l = l0 + 4 * g + r;
+                if (l < L) bio<T>::st(r_xd, l * sr_xd + col * (int)sizeof(T), 0, o[r]);
             }
         }
     }
@@ -175,8 +189,14 @@ __global__ __launch_bounds__(XP_THREADS) void conv_xproj_fwd_kernel(const dm_con
 template <typename T, typename TW, int W, int KSTEPS>
 static void launch_xp(const dm_conv_xproj_fwd_args& a, hipStream_t st) {
     dim3 grid(a.ndir * a.batch), block(XP_THREADS);
-    if (a.flags & DM_FLAG_SILU) hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, true, KSTEPS>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, false, KSTEPS>), grid, block, 0, st, a);
+    const bool silu = (a.flags & DM_FLAG_SILU) != 0;
+    if (a.row_index) {
+        if (silu) hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, true, KSTEPS, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, false, KSTEPS, true>), grid, block, 0, st, a);
+    } else {
+        if (silu) hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, true, KSTEPS, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_xproj_fwd_kernel<T, TW, W, false, KSTEPS, false>), grid, block, 0, st, a);
+    }
 }
 
 template <typename T, typename TW, int W>

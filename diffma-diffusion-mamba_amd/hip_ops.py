@@ -292,9 +292,10 @@ def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out
     return out
 
 
-# Fused conv + x_proj (csrc/conv_xproj.hip): one workgroup walks one gathered sequence, so a launch needs at least a few
-# sequences per CU to fill the chip; below that the unfused pair (chunk-parallel conv + library GEMM) is used.
-XPROJ_FUSED_MIN_SEQS = 256
+# Fused conv + x_proj (csrc/conv_xproj.hip): one workgroup walks one gathered sequence, so a launch needs two sequences per
+# CU to fill the chip (measured, MI355X, D = 1024: 768 sequences 138 vs 207 us, 1536: 274 vs 398 us for the unfused pair,
+# but 192: 58 vs 45 us); below that the unfused pair (chunk-parallel conv + library GEMM) is used.
+XPROJ_FUSED_MIN_SEQS = 512
 
 
 def conv_xproj_supported(x, wx, nseq):
