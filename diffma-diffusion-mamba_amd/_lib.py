@@ -80,6 +80,7 @@ dm_scan_bwd_args = _make_struct("dm_scan_bwd_args")
 dm_conv_fwd_args = _make_struct("dm_conv_fwd_args")
 dm_conv_bwd_args = _make_struct("dm_conv_bwd_args")
 dm_conv_xproj_fwd_args = _make_struct("dm_conv_xproj_fwd_args")
+dm_conv_xproj_bwd_args = _make_struct("dm_conv_xproj_bwd_args")
 dm_merge_args = _make_struct("dm_merge_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
@@ -119,7 +120,7 @@ def load():
                 fn.argtypes = []
             elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
-            elif name == "dm_gather_conv1d_xproj_supported":
+            elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -256,3 +256,237 @@ extern "C" int dm_gather_conv1d_xproj_fwd(const dm_conv_xproj_fwd_args* args, vo
     if (a.io_dtype == DM_BF16) return wf32 ? xp_by_width<bf16_t, float>(a, st) : xp_by_width<bf16_t, bf16_t>(a, st);
     return wf32 ? xp_by_width<f16_t, float>(a, st) : xp_by_width<f16_t, f16_t>(a, st);
 }
+
+namespace dm {
+
+// ====================================================================================================================
+// K4x  dm_gather_conv1d_xproj_bwd -- the mirror image: the gradient entering the conv is
+//          dxc[s][l][:] = du[s][l][:] + dx_dbl[s*L + l][:] @ x_proj.weight          (d x~ = dL/du + W_x^T d x_dbl)
+// The unfused path materialises it with an in-place addmm (reads du, writes dxc: 2 * ndir*B*L*D*s bytes) and conv_bwd reads it
+// back.  Here a workgroup walks one gathered sequence in REVERSE time in tiles of 16 rows: the 16 x 64 dx_dbl tile is
+// multiplied with x_proj.weight on the matrix pipe into an fp32 LDS tile [16][dim], the conv backward of the tile's rows
+// adds du to it on the fly, and everything downstream (act', dw / db accumulation, dx scatter back to token order) happens
+// in the same pass.  dw / db are accumulated in registers over the WHOLE sequence: one partial row per sequence.
+//   wave w owns the output channels [w * dim/8, (w+1) * dim/8) of the product (dim/128 column tiles of 16);
+//   thread t owns channels 2t, 2t+1 of the convolution (32-bit accesses), like K3x.
+template <typename T, typename TW, int W, bool SILU, int D, bool IDX>
+__global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_conv_xproj_bwd_args p) {
+    constexpr int NTW = D / 128;                                      // column tiles (16 channels) per wave
+    constexpr int ROWP = D + 4;                                       // fp32 LDS row stride: rows 4g + r of a D-fragment fall on disjoint banks
+    static_assert(D % 128 == 0 && D <= 2 * XP_THREADS, "dim must be a multiple of 128 and at most 1024");
+    __shared__ __attribute__((aligned(16))) float ptile[XP_TM * ROWP];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g = lane >> 4, ij = lane & 15;
+    const int s = blockIdx.x;
+    const int dir = s / p.batch;
+    const int b = s - dir * p.batch;
+    const int L = p.seqlen;
+    const int P = p.nproj;                                            // multiple of 8, <= 64
+    const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;
+    const bool act = (D == 2 * XP_THREADS) ? true : (2 * tid < D);
+    const int c = act ? 2 * tid : 0;
+    constexpr int ES = (int)sizeof(T);
+    const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)b * p.x_sb);
+    const rsrc_t r_du = make_rsrc((const T*)p.du + (int64_t)s * p.du_ss);
+    const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)s * p.dx_ss);
+    const rsrc_t r_xd = make_rsrc((const T*)p.dxdbl + (int64_t)s * L * p.xd_sr);
+    const rsrc_t r_wt = make_rsrc(p.wxt);                             // [dim][nproj]
+    const int vo = c * ES;
+    const int sl_x = (int)p.x_sl * ES, sl_du = (int)p.du_sl * ES, sl_dx = (int)p.dx_sl * ES, sr_xd = (int)p.xd_sr * ES;
+    const bool k_on[2] = {8 * g < P, 32 + 8 * g < P};                 // this lane's 8-wide K slices inside the projection width
+
+    float w[W][2], bias[2], dw[W][2], db[2], gwin[W - 1][2];          // gwin[k] = g[l + 1 + k] of the rows already processed (later in time)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            w[j][v] = io<TW>::ld((const TW*)p.weight + (int64_t)(c + v) * W + j);
+            dw[j][v] = 0.0f;
+        }
+        bias[v] = p.bias ? io<TW>::ld((const TW*)p.bias + c + v) : 0.0f;
+        db[v] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < W - 1; ++j) gwin[j][v] = 0.0f;
+    }
+
+    const int ntile = (L + XP_TM - 1) / XP_TM;
+    // x rows l0-(W-1) .. l0+15 of a tile (xr[0 .. W-2] = halo); rows before the sequence start are zero
+    constexpr int NXR = XP_TM + W - 1;
+    auto load_x = [&](int l0, uint32_t(&xr)[NXR]) {
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) {
+            const int lr = l0 - (W - 1) + j;
+            int l = lr < 0 ? 0 : (lr < L ? lr : L - 1);
+            const int r = IDX ? idx[l] : l;
+            xr[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo, r * sl_x, 0);
+        }
+    };
+    auto load_du_half = [&](int l0, int h, uint32_t(&dur)[XP_TM]) {
+#pragma unroll
+        for (int j = h * (XP_TM / 2); j < (h + 1) * (XP_TM / 2); ++j) {
+            int l = l0 + j;
+            l = l < L ? l : L - 1;
+            dur[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo, l * sl_du, 0);
+        }
+    };
+    uint32_t xr[NXR], dur[XP_TM];
+    load_du_half((ntile - 1) * XP_TM, 0, dur);
+    load_du_half((ntile - 1) * XP_TM, 1, dur);
+
+    for (int t = ntile - 1; t >= 0; --t) {
+        const int l0 = t * XP_TM;
+        // ---- product tile on the matrix pipe: ptile[i][n] = sum_k dx_dbl[l0 + i][k] * Wx[k][n]  (rows past L are zero) ----
+        xp_u32x4 afrag[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            afrag[kk] = (xp_u32x4){0u, 0u, 0u, 0u};
+            if (k_on[kk] && l0 + ij < L) {
+                const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES, 0, 0);
+                afrag[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
+            }
+        }
+        load_x(l0, xr);                                                // consumed after the barrier: in flight during the product
+#pragma unroll 2
+        for (int n = 0; n < NTW; ++n) {
+            const int ch = (wave * NTW + n) * 16 + ij;                 // B[k][j] = Wx[k][ch] = wxt[ch][k]: lane (g, j) reads wxt[ch][32kk + 8g .. +7]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                xp_u32x4 bf = (xp_u32x4){0u, 0u, 0u, 0u};
+                if (k_on[kk]) {
+                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_wt, (ch * P + 32 * kk + 8 * g) * ES, 0, 0);
+                    bf = (xp_u32x4){q[0], q[1], q[2], q[3]};
+                }
+                acc = xp_mfma<T>::run(afrag[kk], bf, acc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ptile[(4 * g + r) * ROWP + (wave * NTW + n) * 16 + ij] = acc[r];
+        }
+        __syncthreads();
+        // ---- conv backward of the tile's rows, last row first ----
+#pragma unroll
+        for (int h = 1; h >= 0; --h) {
+#pragma unroll
+            for (int j = (h + 1) * (XP_TM / 2) - 1; j >= h * (XP_TM / 2); --j) {
+                const int l = l0 + j;
+                const bool valid = l < L;                              // wave-uniform
+                const f32x2 pv = *reinterpret_cast<const f32x2*>(&ptile[j * ROWP + c]);
+                float duv[2], xw[W][2];
+                xp_mfma<T>::unpack(dur[j], duv[0], duv[1]);
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    xp_mfma<T>::unpack(xr[j + k], xw[k][0], xw[k][1]);
+                    if (l - (W - 1) + k < 0) { xw[k][0] = 0.0f; xw[k][1] = 0.0f; }
+                }
+                float gv[2], dxv[2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    gv[v] = valid ? (v == 0 ? pv.x : pv.y) + duv[v] : 0.0f;
+                    if (SILU) {
+                        float pre = bias[v];
+#pragma unroll
+                        for (int k = 0; k < W; ++k) pre += w[k][v] * xw[k][v];
+                        const float sg = sigmoid_f(pre);
+                        gv[v] *= sg * (1.0f + pre * (1.0f - sg));
+                    }
+#pragma unroll
+                    for (int k = 0; k < W; ++k) dw[k][v] += gv[v] * xw[k][v];
+                    db[v] += gv[v];
+                    dxv[v] = w[W - 1][v] * gv[v];                      // dx[m] = sum_j w[j] * g[m + (W-1) - j]
+#pragma unroll
+                    for (int k = 0; k < W - 1; ++k) dxv[v] += w[W - 2 - k][v] * gwin[k][v];
+#pragma unroll
+                    for (int k = W - 2; k > 0; --k) gwin[k][v] = gwin[k - 1][v];
+                    if (W > 1) gwin[0][v] = gv[v];
+                }
+                if (valid && act) {
+                    const int r = IDX ? idx[l] : l;
+                    __builtin_amdgcn_raw_buffer_store_b32(xp_mfma<T>::pack(dxv[0], dxv[1]), r_dx, vo, r * sl_dx, 0);
+                }
+            }
+            if (t > 0) load_du_half(l0 - XP_TM, h, dur);
+        }
+        __syncthreads();                                               // ptile is rewritten by the next tile's product
+    }
+    if (act) {
+        float* dwp = p.dw_partial + ((int64_t)s * D + c) * W;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) dwp[v * W + k] = dw[k][v];
+            if (p.db_partial) p.db_partial[(int64_t)s * D + c + v] = db[v];
+        }
+    }
+}
+
+template <typename T, typename TW, int W, int D>
+static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
+    dim3 grid(a.ndir * a.batch), block(XP_THREADS);
+    const bool silu = (a.flags & DM_FLAG_SILU) != 0;
+    if (a.row_index) {
+        if (silu) hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, false, D, true>), grid, block, 0, st, a);
+    } else {
+        if (silu) hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, false, D, false>), grid, block, 0, st, a);
+    }
+}
+
+template <typename T, typename TW, int W>
+static int xpb_by_dim(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
+    switch (a.dim) {
+        case 1024: launch_xpb<T, TW, W, 1024>(a, st); break;
+#ifndef DM_FAST_BUILD
+        case 512: launch_xpb<T, TW, W, 512>(a, st); break;
+        case 256: launch_xpb<T, TW, W, 256>(a, st); break;
+#endif
+        case 128: launch_xpb<T, TW, W, 128>(a, st); break;
+        default: set_error("dm_gather_conv1d_xproj_bwd: dim %d not instantiated (128, 256, 512, 1024)", a.dim); return DM_ERR_ARG;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_gather_conv1d_xproj_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+
+template <typename T, typename TW>
+static int xpb_by_width(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
+    switch (a.width) {
+        case 4: return xpb_by_dim<T, TW, 4>(a, st);
+#ifndef DM_FAST_BUILD
+        case 3: return xpb_by_dim<T, TW, 3>(a, st);
+        case 2: return xpb_by_dim<T, TW, 2>(a, st);
+#endif
+        default: set_error("dm_gather_conv1d_xproj_bwd: width %d not in {2,3,4}", a.width); return DM_ERR_ARG;
+    }
+}
+
+}  // namespace dm
+
+extern "C" int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype) {
+    const bool d_ok = dim == 128 || dim == 256 || dim == 512 || dim == 1024;
+    return (d_ok && nproj >= 8 && nproj <= 64 && nproj % 8 == 0 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;
+}
+
+extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_gather_conv1d_xproj_bwd: null args"); return DM_ERR_ARG; }
+    const dm_conv_xproj_bwd_args& a = *args;
+    if (!a.x || !a.weight || !a.du || !a.dxdbl || !a.wxt || !a.dx || !a.dw_partial) { set_error("dm_gather_conv1d_xproj_bwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_xproj_bwd: non-positive size"); return DM_ERR_ARG; }
+    if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_xproj_bwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
+    if (!dm_gather_conv1d_xproj_bwd_supported(a.dim, a.nproj, a.io_dtype)) {
+        set_error("dm_gather_conv1d_xproj_bwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj a multiple of 8 <= 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
+        return DM_ERR_ARG;
+    }
+    if (a.x_sd != 1 || a.du_sd != 1 || a.dx_sd != 1) { set_error("dm_gather_conv1d_xproj_bwd: needs token-major tensors"); return DM_ERR_LAYOUT; }
+    const bool odd = ((uintptr_t)a.x & 3) || (a.x_sb & 1) || (a.x_sl & 1) || ((uintptr_t)a.du & 3) || (a.du_ss & 1) || (a.du_sl & 1) ||
+                     ((uintptr_t)a.dx & 3) || (a.dx_ss & 1) || (a.dx_sl & 1) || ((uintptr_t)a.dxdbl & 15) || (a.xd_sr & 7) || ((uintptr_t)a.wxt & 15);
+    if (odd) { set_error("dm_gather_conv1d_xproj_bwd: x / du / dx need 4-byte aligned rows, dxdbl and wxt 16-byte aligned rows"); return DM_ERR_LAYOUT; }
+    hipStream_t st = (hipStream_t)stream;
+    const bool wf32 = a.w_dtype == DM_F32;
+    if (!wf32 && a.w_dtype != a.io_dtype) { set_error("dm_gather_conv1d_xproj_bwd: w_dtype must be fp32 or io_dtype"); return DM_ERR_DTYPE; }
+    if (a.io_dtype == DM_BF16) return wf32 ? xpb_by_width<bf16_t, float>(a, st) : xpb_by_width<bf16_t, bf16_t>(a, st);
+    return wf32 ? xpb_by_width<f16_t, float>(a, st) : xpb_by_width<f16_t, f16_t>(a, st);
+}

@@ -6,11 +6,13 @@ reference-facing operator names live in selective_scan_interface.py.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -336,6 +338,61 @@ def gather_conv1d_xproj_fwd(x, weight, bias, wx, *, row_index=None, ndir=1, silu
     es = x.element_size()
     _launch("dm_gather_conv1d_xproj_fwd", a, x, 2 * ndir * Bsz * L * Dm * es + ndir * Bsz * L * P * es + P * Dm * es)
     return out, xdbl
+
+
+# K4x (conv backward fused with d x~ = du + dx_dbl @ Wx) is parity-green but NOT faster yet (MI355X, D = 1024, 1536 sequences:
+# 837 us against 704 us for the in-place addmm + conv_bwd pair: the conv backward is VALU-bound, ~55 instructions per row and
+# channel pair, and the fused form adds the product tile's LDS round trip and per-tile weight-fragment loads): opt-in.
+XPROJ_FUSED_BWD = os.environ.get("DIFFMA_FUSED_CONV_BWD") == "1"
+
+
+def conv_xproj_bwd_supported(x, wx, nseq):
+    """True when dm_gather_conv1d_xproj_bwd serves this call (as the forward, plus a projection width that is a multiple of 8)."""
+    if not XPROJ_FUSED_BWD:
+        return False
+    if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or nseq < XPROJ_FUSED_MIN_SEQS:
+        return False
+    if x.stride(0) % 2 or x.stride(1) % 2 or x.storage_offset() % 2:
+        return False
+    return bool(_lib.load().dm_gather_conv1d_xproj_bwd_supported(int(x.shape[-1]), int(wx.shape[0]), dtype_code(x)))
+
+
+def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, ndir=1, silu=True):
+    """Conv backward whose incoming gradient is du + dxdbl @ wx, formed tile by tile inside the kernel (never materialised).
+    x: [B, L, Dm] view; du: [ndir*B, L, Dm]; dxdbl: [ndir*B*L, P] (row stride any multiple of 8); wxt: [Dm, P] = x_proj.weight^T.
+    Returns (dx_slabs [ndir*B, L, Dm] in token order, dweight [Dm, W] fp32, dbias [Dm] fp32)."""
+    _require_gpu(x, weight, bias, du, dxdbl, wxt)
+    Bsz, L, Dm = x.shape
+    W = weight.shape[-1]
+    P = wxt.shape[1]
+    weight = weight.reshape(Dm, W).contiguous()
+    if weight.dtype != x.dtype and weight.dtype != torch.float32:
+        weight = weight.float()
+    if bias is not None:
+        bias = bias.to(weight.dtype).contiguous()
+    wxt = wxt.contiguous()
+    assert wxt.dtype == x.dtype and wxt.shape[0] == Dm and dxdbl.dtype == x.dtype and du.dtype == x.dtype
+    assert dxdbl.stride(1) == 1 and du.stride(2) == 1
+    S = ndir * Bsz
+    dev = x.device
+    dx = torch.empty((S, L, Dm), dtype=x.dtype, device=dev)
+    dw = torch.empty((S, Dm, W), dtype=torch.float32, device=dev)
+    db = torch.empty((S, Dm), dtype=torch.float32, device=dev)
+    a = dm_conv_xproj_bwd_args()
+    a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
+    a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
+    a.flags = DM_FLAG_SILU if silu else 0
+    a.nproj = P
+    a.x, a.weight, a.bias, a.row_index = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index)
+    a.du, a.dxdbl, a.wxt = _ptr(du), _ptr(dxdbl), _ptr(wxt)
+    a.dx, a.dw_partial, a.db_partial = _ptr(dx), _ptr(dw), _ptr(db)
+    a.x_sb, a.x_sl, a.x_sd = x.stride()
+    a.du_ss, a.du_sl, a.du_sd = du.stride()
+    a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
+    a.xd_sr = dxdbl.stride(0)
+    es = x.element_size()
+    _launch("dm_gather_conv1d_xproj_bwd", a, x, 3 * S * L * Dm * es + S * L * P * es + P * Dm * es)
+    return dx, colsum(dw.view(S, Dm * W)).view(Dm, W), colsum(db)
 
 
 def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=True):

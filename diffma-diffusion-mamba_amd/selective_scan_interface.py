@@ -288,10 +288,15 @@ class _SpiralSSMFn(torch.autograd.Function):
         dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
-        # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
-        dxc = GemmChain.run(du.view(M, Din).addmm_, dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
-        dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
-                                                               row_index=scan_index, ndir=ndir, silu=True)
+        if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz):
+            # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]
+            dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_xproj_bwd(xz[..., :Din], conv_w, conv_b, du, dx_dbl, Wx_c.t().contiguous(),
+                                                                         row_index=scan_index, ndir=ndir, silu=True)
+        else:
+            # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
+            dxc = GemmChain.run(du.view(M, Din).addmm_, dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
+            dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
+                                                                   row_index=scan_index, ndir=ndir, silu=True)
         dxz = torch.empty_like(xz)
         hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
         hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])

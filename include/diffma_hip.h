@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 10
+#define DM_ABI_VERSION 11
 
 typedef enum {
     DM_OK = 0,
@@ -227,6 +227,34 @@ typedef struct {
 
 int dm_gather_conv1d_xproj_fwd(const dm_conv_xproj_fwd_args *args, void *stream);
 int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype);
+
+/* Backward of the conv FUSED with the x_proj input gradient: the gradient entering the conv is
+ *   dxc[s][l][:] = du[s][l][:] + dxdbl[s*seqlen + l][:] @ wx            (d x~ = dL/du + d x_dbl . x_proj.weight)
+ * and is never materialised (the unfused path runs an in-place addmm over [ndir*batch*seqlen][dim] first).  Otherwise as
+ * dm_gather_conv1d_bwd: dx in token order per direction; dw_partial [ndir*batch][dim][width], db_partial [ndir*batch][dim]
+ * fp32 -- ONE partial row per sequence.  wxt: x_proj.weight TRANSPOSED, [dim][nproj] contiguous, io dtype; nproj % 8 == 0.
+ */
+typedef struct {
+    int32_t batch, dim, seqlen, width, ndir;
+    int32_t io_dtype, w_dtype;
+    int32_t flags;
+    int32_t nproj;
+    int32_t _pad;
+    const void *x, *weight, *bias;
+    const int32_t *row_index;
+    const void *du;           /* [ndir*batch][seqlen][dim] io dtype */
+    const void *dxdbl;        /* [ndir*batch*seqlen][*] io dtype, row stride xd_sr */
+    const void *wxt;          /* [dim][nproj] io dtype */
+    void *dx;                 /* [ndir*batch][seqlen][dim] io dtype, token order */
+    float *dw_partial, *db_partial;
+    int64_t x_sb, x_sl, x_sd;
+    int64_t du_ss, du_sl, du_sd;
+    int64_t dx_ss, dx_sl, dx_sd;
+    int64_t xd_sr;
+} dm_conv_xproj_bwd_args;
+
+int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args *args, void *stream);
+int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * Token merge: out[b][t][c] = sum_k in[k][b][ idx[k][t] ][c]     (idx NULL = identity).

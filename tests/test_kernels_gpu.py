@@ -269,6 +269,48 @@ def test_fused_conv_xproj_fwd_matches_oracle(gpu, dtype, Bsz, L, Dm, P, W, with_
     torch.testing.assert_close(xdbl.float().cpu().double(), ref_dbl, rtol=rtol, atol=atol * max(1.0, ref_dbl.abs().max().item()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,P,W,with_idx", [(2, 196, 1024, 64, 4, True), (3, 49, 128, 40, 4, True), (1, 16, 128, 64, 4, False),
+                                                   (2, 37, 256, 48, 3, True), (1, 1, 512, 16, 2, False), (2, 5, 1024, 8, 4, True)])
+def test_fused_conv_xproj_bwd_matches_oracle_autograd(gpu, dtype, Bsz, L, Dm, P, W, with_idx):
+    """K4x: conv backward with the incoming gradient du + dx_dbl @ Wx formed in the kernel, against fp64 autograd of
+    loss = <du, x~> + <dx_dbl, x~ @ Wx^T> through the oracle conv: dx per direction (token order), dweight, dbias."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import causal_conv1d_ref
+
+    g = torch.Generator().manual_seed(L * 5 + Dm + P)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g).to(dtype)
+    w = torch.randn(Dm, W, generator=g) * 0.5
+    b = torch.randn(Dm, generator=g) * 0.1
+    wx = (torch.randn(P, Dm, generator=g) * 0.1).to(dtype)
+    ndir = 3 if with_idx else 1
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    du = torch.randn(ndir * Bsz, L, Dm, generator=g).to(dtype)
+    dxdbl = torch.randn(ndir * Bsz * L, P, generator=g).to(dtype)
+    dx, dw, db = hip_ops.gather_conv1d_xproj_bwd(xz.to(gpu)[..., :Dm], w.to(gpu), b.to(gpu), du.to(gpu), dxdbl.to(gpu),
+                                                 wx.to(gpu).t().contiguous(), row_index=perms.to(gpu) if with_idx else None, ndir=ndir)
+    torch.cuda.synchronize()
+    x = xz[..., :Dm].float().double().clone().requires_grad_(True)
+    wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    wx64 = wx.float().double()
+    loss, per_dir = 0, []
+    for k in range(ndir):
+        xs = x[:, perms[k].long(), :]
+        y = causal_conv1d_ref(xs.permute(0, 2, 1), wd, bd, activation="silu").permute(0, 2, 1)          # [B, L, Dm]
+        lk = (y * du.view(ndir, Bsz, L, Dm)[k].float().double()).sum() + ((y.reshape(-1, Dm) @ wx64.t()) * dxdbl.view(ndir, Bsz * L, P)[k].float().double()).sum()
+        per_dir.append(torch.autograd.grad(lk, x, retain_graph=True)[0])
+        loss = loss + lk
+    loss.backward()
+    rtol, atol = {torch.bfloat16: (3e-2, 5e-2), torch.float16: (4e-3, 8e-3)}[dtype]
+    got = dx.float().cpu().double().view(ndir, Bsz, L, Dm)
+    for k in range(ndir):
+        sc = max(1.0, per_dir[k].abs().max().item())
+        torch.testing.assert_close(got[k], per_dir[k], rtol=rtol, atol=atol * sc, msg=lambda m, k=k: f"dx dir {k}: {m}")
+    sc = max(1.0, wd.grad.abs().max().item())
+    torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=rtol, atol=atol * sc * 0.2)
+    torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=rtol, atol=atol * sc * 0.2)
+
+
 def test_token_merge_exact(gpu):
     from diffma_amd import hip_ops
 

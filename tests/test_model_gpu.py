@@ -95,7 +95,7 @@ def test_training_step_gradients_match_oracle_autograd(gpu):
     assert len(got) == sum(1 for k in sd64 if k != "pos_embed")
 
 
-def _mixer_case(gpu, dtype, tol):
+def _mixer_case(gpu, dtype, tol, d_model=64):
     from diffma_amd.mamba import Mamba
     from diffma_amd.tools import spiral
     from oracle.mamba_ref import mamba_spiral_forward_ref
@@ -104,13 +104,13 @@ def _mixer_case(gpu, dtype, tol):
     n = 4
     orders, inverses = spiral(n)
     lists = (orders[2], orders[3], inverses[2], inverses[3])
-    mix = Mamba(d_model=64, d_state=16, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+    mix = Mamba(d_model=d_model, d_state=16, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
                 origina_list_reversal=lists[3]).to(gpu)
     with torch.no_grad():
         mix.A_log.add_(torch.randn_like(mix.A_log) * 0.2)
         mix.D.add_(torch.randn_like(mix.D) * 0.2)
-    x = torch.randn(3, n * n, 64, device=gpu, requires_grad=True)
-    dy = torch.randn(3, n * n, 64, device=gpu)
+    x = torch.randn(3, n * n, d_model, device=gpu, requires_grad=True)
+    dy = torch.randn(3, n * n, d_model, device=gpu)
     with torch.autocast("cuda", dtype=dtype, enabled=dtype != torch.float32):
         y = mix(x, "spiral")
     (y.float() * dy).sum().backward()
@@ -646,10 +646,20 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
         calls["n"] += 1
         return real(*a, **k)
 
+    real_b = hip_ops.gather_conv1d_xproj_bwd
+
+    def counted_b(*a, **k):
+        calls["b"] = calls.get("b", 0) + 1
+        return real_b(*a, **k)
+
     monkeypatch.setattr(hip_ops, "XPROJ_FUSED_MIN_SEQS", 1)
+    monkeypatch.setattr(hip_ops, "XPROJ_FUSED_BWD", True)
     monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_fwd", counted)
-    _mixer_case(gpu, torch.bfloat16, 2e-2)
+    monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_bwd", counted_b)
+    _mixer_case(gpu, torch.bfloat16, 2e-2)          # d_model 64: dim 128, 36 projection rows -> fused forward, unfused backward
     assert calls["n"] >= 1
+    _mixer_case(gpu, torch.bfloat16, 2e-2, d_model=128)   # dim 256, 8 + 32 = 40 projection rows -> both fused kernels
+    assert calls.get("b", 0) >= 1
     g, sd, net, inp = _g5(gpu)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         out = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).float().cpu()

@@ -54,3 +54,33 @@ t_un, t_fu = timeit(unfused), timeit(fused)
 nb = 2 * 3 * B * L * Dm * 2 + 3 * B * L * P * 2
 print(json.dumps(dict(B=B, conv_only_us=round(t_conv, 1), unfused_pair_us=round(t_un, 1), fused_us=round(t_fu, 1),
                       fused_GBps=round(nb / t_fu / 1e3, 1))))
+
+# ---- backward: in-place addmm + conv_bwd against the fused K4x --------------------------------------------------------
+S = 3 * B
+du = torch.randn(S, L, Dm, device=dev).to(dt)
+dxd = torch.randn(S * L, P, device=dev).to(dt)
+wxt = wx.t().contiguous()
+
+
+def unfused_b():
+    dxc = du.clone().view(-1, Dm).addmm_(dxd, wx).view(S, L, Dm)
+    return hip_ops.gather_conv1d_bwd(xz[..., :Dm], w, b, dxc, row_index=idx, ndir=3)
+
+
+def unfused_b_noclone():      # what the model does: addmm_ in place on du (du is consumed)
+    scratch = du                # timing only: the values drift, the traffic is the same
+    dxc = scratch.view(-1, Dm).addmm_(dxd, wx, beta=1.0, alpha=0.0).view(S, L, Dm)
+    return hip_ops.gather_conv1d_bwd(xz[..., :Dm], w, b, dxc, row_index=idx, ndir=3)
+
+
+def fused_b():
+    return hip_ops.gather_conv1d_xproj_bwd(xz[..., :Dm], w, b, du, dxd, wxt, row_index=idx, ndir=3)
+
+
+ra, rc = unfused_b(), fused_b()
+for name, x0, x1 in zip(("dx", "dw", "db"), ra, rc):
+    d = (x0.float() - x1.float()).abs()
+    print(f"  bwd {name}: max abs diff {float(d.max()):.4g} (scale {float(x0.float().abs().max()):.3g})")
+t_cb = timeit(lambda: hip_ops.gather_conv1d_bwd(xz[..., :Dm], w, b, du, row_index=idx, ndir=3))
+t_ub, t_fb = timeit(unfused_b_noclone), timeit(fused_b)
+print(json.dumps(dict(B=B, conv_bwd_only_us=round(t_cb, 1), unfused_bwd_pair_us=round(t_ub, 1), fused_bwd_us=round(t_fb, 1))))
