@@ -23,6 +23,8 @@ DM_FLAG_DELTA_SOFTPLUS = 1
 DM_FLAG_SILU = 2
 DM_FLAG_DOUT_PER_SEQ = 4
 DM_FLAG_A_SHARED = 8
+DM_FLAG_SCAN_SEQUENTIAL = 16
+DM_FLAG_SCAN_CHUNKED = 32
 
 _SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 
@@ -120,6 +122,8 @@ def load():
                 fn.argtypes = []
             elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
+            elif name == "dm_scan_bwd_launch_group_channels":
+                fn.argtypes = [ctypes.c_int] * 5
             elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
             else:

@@ -1,7 +1,7 @@
 // scan_bwd: f32 I/O instantiations (split per dtype so the library builds in parallel)
-#include "scan_bwd_impl.h"
+#include "scan_bwd_chunked.h"
 namespace dm {
-int scan_bwd_f32(const dm_scan_bwd_args& a, hipStream_t st) { return bwd_dispatch_bc<float>(a, st); }
+int scan_bwd_f32(const dm_scan_bwd_args& a, hipStream_t st) { return bwd_dispatch<float>(a, st); }
 }  // namespace dm
 
 extern "C" int dm_scan_bwd_group_channels(int dstate) {
@@ -16,3 +16,9 @@ extern "C" int dm_scan_bwd_group_channels(int dstate) {
     }
 }
 
+// channels per dB/dC partial row for THIS launch: 64 when the chunk-parallel kernel (scan_bwd_chunked.h) will take it,
+// dm_scan_bwd_group_channels(dstate) otherwise.  The host sizes dBC_partial [nseq][seqlen][ceil(dim/GC)][2*dstate] with it.
+extern "C" int dm_scan_bwd_launch_group_channels(int nseq, int dim, int seqlen, int dstate, int flags) {
+    if (dm::bwd_chunked_lc(nseq, dim, seqlen, dstate, flags) > 0) return dm::WAVE;
+    return dm_scan_bwd_group_channels(dstate);
+}

@@ -170,7 +170,8 @@ constexpr int CHUNKED_NW = 14, CHUNKED_LC = 14;          // 14 waves x 14 steps:
 // The 137 KB of LDS allow one workgroup per CU, i.e. 256 at a time: measured (bf16, dim 1024, L 196) 75 -> 24 us at
 // nseq 3, 78 -> 50 us at nseq 24 (two rounds), break-even near nseq 48.
 static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
-    static const int forced = [] { const char* e = getenv("DM_SCAN_CHUNKED"); return e ? atoi(e) : -1; }();   // 0 / 1: developer override
+    static const int env = [] { const char* e = getenv("DM_SCAN_CHUNKED"); return e ? atoi(e) : -1; }();   // 0 / 1: developer override
+    const int forced = (a.flags & DM_FLAG_SCAN_SEQUENTIAL) ? 0 : ((a.flags & DM_FLAG_SCAN_CHUNKED) ? 1 : env);
     if (forced == 0) return false;
     const int64_t waves = (int64_t)a.nseq * ((a.dim + WAVE - 1) / WAVE);
     if (a.ckpt && !(a.z && a.z_row_index && (a.flags & DM_FLAG_DELTA_SOFTPLUS))) return false;   // checkpoints: model call pattern only

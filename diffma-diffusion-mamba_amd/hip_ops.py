@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -149,9 +149,16 @@ def scan_bwd_algorithmic_bytes(S, Dm, L, N, es, has_z=True):
     return (7 if has_z else 5) * S * Dm * L * es + 2 * S * N * L * 4
 
 
+def _variant_flag(variant):
+    """variant: None = the library chooses by launch size; "sequential" / "chunked" force a kernel family (tests, A/B runs)."""
+    if variant is None:
+        return 0
+    return {"sequential": DM_FLAG_SCAN_SEQUENTIAL, "chunked": DM_FLAG_SCAN_CHUNKED}[variant]
+
+
 def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
-             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False):
+             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False, variant=None):
     """u, delta: [S, L, Dm] token-major (last stride 1).  Bm, Cm: [S, L, G*N] views (state stride 1).
     z: [S or S/ndir, Lz, Dm] or None.  A: [Dm, N] fp32.  Returns out [S, L, Dm] (allocated if None)."""
     _require_gpu(u, delta, A, Bm, Cm, z)
@@ -168,7 +175,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.batch_per_dir = batch_per_dir
     a.io_dtype = dtype_code(u)
     a.bc_dtype = dtype_code(Bm)
-    a.flags = (DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_A_SHARED if a_shared else 0)
+    a.flags = (DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_A_SHARED if a_shared else 0) | _variant_flag(variant)
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
@@ -193,14 +200,16 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
 
 def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
-             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False, dbc_out=None):
+             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False, dbc_out=None, variant=None):
     """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
     already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
     z_row_index is given)."""
     _require_gpu(u, delta, A, Bm, Cm, z, dout, ckpt)
     S, L, Dm = u.shape
     N = A.shape[1]
-    gc = _lib.load().dm_scan_bwd_group_channels(N)
+    flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_DOUT_PER_SEQ if dout_per_seq else 0)
+             | (DM_FLAG_A_SHARED if a_shared else 0) | _variant_flag(variant))
+    gc = _lib.load().dm_scan_bwd_launch_group_channels(S, Dm, L, N, flags)   # 256 (sequential kernel) or 64 (chunk-parallel, small launches)
     if gc <= 0:
         raise _lib.DiffmaHipError(f"selective-scan backward is not built for d_state={N}")
     nw = (Dm + gc - 1) // gc
@@ -221,8 +230,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.batch_per_dir = batch_per_dir
     a.io_dtype = dtype_code(u)
     a.bc_dtype = dtype_code(Bm)
-    a.flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_DOUT_PER_SEQ if dout_per_seq else 0)
-               | (DM_FLAG_A_SHARED if a_shared else 0))
+    a.flags = flags
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.dout = _ptr(u), _ptr(delta), _ptr(z), _ptr(dout)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 11
+#define DM_ABI_VERSION 12
 
 typedef enum {
     DM_OK = 0,
@@ -49,9 +49,12 @@ enum {
     DM_FLAG_A_SHARED = 8,       /* scan: A[d][n] is the same for every state n of a channel (Mamba-2 / SSD: one decay per
                                    head), so the kernels evaluate ONE exp per (channel, step) instead of dstate.  A is still
                                    passed as [dim][dstate]; the caller vouches for the property.                         */
-    DM_FLAG_DOUT_PER_SEQ = 4    /* scan bwd with row indices: dout is [nseq][row][d] (one gradient per direction,
+    DM_FLAG_DOUT_PER_SEQ = 4,   /* scan bwd with row indices: dout is [nseq][row][d] (one gradient per direction,
                                    Mamba-2: the gated RMSNorm sits between the scan and the merge) instead of
                                    [batch_per_dir][row][d] shared by the directions  */
+    DM_FLAG_SCAN_SEQUENTIAL = 16, /* scan fwd / bwd: take the sequential-in-time kernel whatever the launch size          */
+    DM_FLAG_SCAN_CHUNKED = 32   /* scan fwd / bwd: take the chunk-parallel (two-pass) kernel where it is instantiated;
+                                   by default the library chooses by launch size (small launches are latency-bound)       */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -150,7 +153,11 @@ typedef struct {
 } dm_scan_bwd_args;
 
 int dm_selective_scan_bwd(const dm_scan_bwd_args *args, void *stream);
-int dm_scan_bwd_group_channels(int dstate);   /* GC above; <= 0 if dstate is not instantiated */
+int dm_scan_bwd_group_channels(int dstate);   /* GC of the sequential kernel; <= 0 if dstate is not instantiated */
+/* GC of THIS launch: small launches (graphed small-batch training) take a chunk-parallel kernel -- NW waves per (sequence,
+ * 64 channels), each owning a run of time steps, two passes joined by the linearity of the adjoint carry -- which writes
+ * one dB/dC partial row per 64 channels; size dBC_partial with this value. */
+int dm_scan_bwd_launch_group_channels(int nseq, int dim, int seqlen, int dstate, int flags);
 
 /* ------------------------------------------------------------------------------------------------
  * Token gather + causal depthwise conv1d (+bias, +SiLU), forward.  Replaces

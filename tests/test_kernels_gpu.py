@@ -327,7 +327,8 @@ def test_token_merge_exact(gpu):
     assert torch.equal(out2, (slabs[0] + slabs[1]) + slabs[2])
 
 
-def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None, a_shared=False, dout_per_seq=False):
+def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None, a_shared=False, dout_per_seq=False,
+                   variant="sequential"):
     """a_shared: A[d, :] is one value per channel and the kernels run their DM_FLAG_A_SHARED form (one exp per channel-step, the
     Mamba-2 call pattern); dout_per_seq: the incoming gradient is per direction [S, L, Dm] in token order, read through
     out_row_index (DM_FLAG_DOUT_PER_SEQ) instead of one merged gradient per batch element."""
@@ -354,10 +355,13 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
     else:
         zdev = d["z"]
         dout = torch.randn(S, L, Dm, generator=g).to(dtype)
+    # variant: the kernel family under test (both the forward that writes the checkpoints and the backward); the library's own
+    # choice by launch size would send every small test shape to the chunk-parallel kernels
+    fwd_variant = variant if (variant != "chunked" or (16 * 14 // 4 < L <= 196 and N == 16)) else "sequential"
     out = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], True,
-                           ckpt=ckpt, ckpt_every=K, a_shared=a_shared, **kw)
+                           ckpt=ckpt, ckpt_every=K, a_shared=a_shared, variant=fwd_variant, **kw)
     res = hip_ops.scan_bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zdev, d["bias"], dout.to(gpu), ckpt,
-                           True, ckpt_every=K, a_shared=a_shared, dout_per_seq=dout_per_seq, **kw)
+                           True, ckpt_every=K, a_shared=a_shared, dout_per_seq=dout_per_seq, variant=variant, **kw)
     torch.cuda.synchronize()
     du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
 
@@ -442,6 +446,43 @@ def test_scan_bwd_bench_instantiation(gpu, dtype, L):
     sums dB/dC on the matrix pipe), 3 directions through row-index tables sharing z and the merged dout, checkpoints in the
     dtype's own format -- backward AND forward of that launch against fp64 autograd of the oracle."""
     _scan_bwd_case(gpu, dtype, 6, L, 1024, 16, seed=100 + L, indexed=True, Bsz=2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S,L,Dm,kw", [
+    (6, 196, 1024, dict(indexed=True, Bsz=2)),                    # the model's call at batch 2: 7 waves x 28 steps
+    (3, 183, 128, dict(indexed=True, Bsz=1)),                     # ragged: the last chunk is partial, and so is its last sub-chunk
+    (2, 196, 200, dict()),                                        # no index tables, ragged channel count
+    (2, 100, 64, dict(with_z=False)),                             # chunks past the end of the sequence, no gate
+    (6, 49, 256, dict(indexed=True, Bsz=2)),                      # L = 49 (DiffMa-*/4): 7 waves x 8 steps
+    (2, 30, 128, dict()),
+    (3, 196, 256, dict(indexed=True, Bsz=1, a_shared=True, dout_per_seq=True)),   # the Mamba-2 call pattern
+])
+def test_scan_bwd_chunk_parallel_variant(gpu, dtype, S, L, Dm, kw):
+    """K2c (csrc/scan_bwd_chunked.h): NW waves per (sequence, 64 channels), two passes joined by the linearity of the adjoint
+    carry -- every gradient against fp64 autograd of the oracle, same tolerances as the sequential kernel."""
+    _scan_bwd_case(gpu, dtype, S, L, Dm, 16, seed=7 * L + Dm, variant="chunked", **kw)
+
+
+def test_scan_bwd_variants_agree_and_default_choice(gpu):
+    """The library's own choice: a small launch takes the chunk-parallel kernel (partial rows per 64 channels), a large one the
+    sequential kernel (per 256); both give the same gradients up to fp32 summation order."""
+    from diffma_amd import _lib, hip_ops
+
+    lib = _lib.load()
+    assert lib.dm_scan_bwd_launch_group_channels(24, 1024, 196, 16, 0) == 64
+    assert lib.dm_scan_bwd_launch_group_channels(768, 1024, 196, 16, 0) == 256
+    assert lib.dm_scan_bwd_launch_group_channels(24, 1024, 196, 16, _lib.DM_FLAG_SCAN_SEQUENTIAL) == 256
+    assert lib.dm_scan_bwd_launch_group_channels(24, 1024, 16, 16, 0) == 256          # too short to cut
+    S, L, Dm, N = 4, 196, 256, 16
+    host, d = _inputs(S, L, Dm, N, torch.float32, seed=77, dev=gpu)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, torch.float32, gpu)
+    hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["bias"], True, ckpt=ckpt)
+    dout = torch.randn(S, L, Dm, generator=torch.Generator().manual_seed(3)).to(gpu)
+    ra = hip_ops.scan_bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["bias"], dout, ckpt, True, variant="sequential")
+    rb = hip_ops.scan_bwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], d["z"], d["bias"], dout, ckpt, True)      # library's choice: chunked
+    for name, x0, x1 in zip(("du", "ddelta", "dz", "dB", "dC", "dA", "dD", "dbias"), ra, rb):
+        torch.testing.assert_close(x1, x0, rtol=2e-4, atol=2e-5 * max(1.0, x0.abs().max().item()), msg=lambda m, n=name: f"{n}: {m}")
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])

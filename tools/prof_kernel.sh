@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; KERN=$2; shift 2
-OUT=$R/gpurun_out/pmc_$TAG
-mkdir -p $OUT
+OUT=/tmp/pmc_$TAG          # raw rocprof output stays on the box; the caller redirects the printed summary into gpurun_out/
+rm -rf $OUT; mkdir -p $OUT
 run() { rocprofv3 --kernel-trace "$@" ; }
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d $OUT/p1 -o k -- python $R/tools/bench_kernels.py --iters 3 "$@" > $OUT/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE -d $OUT/p2 -o k -- python $R/tools/bench_kernels.py --iters 3 "$@" > $OUT/p2.log 2>&1

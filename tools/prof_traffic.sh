@@ -2,11 +2,11 @@
 # HBM traffic (FETCH_SIZE / WRITE_SIZE, separate PMC passes) of the scan kernels at the bench shape. Run on the GPU box.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/traffic
-mkdir -p $OUT
+OUT=/tmp/traffic
+rm -rf $OUT; mkdir -p $OUT
 for dt in bf16 fp32; do
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd > $OUT/f_$dt.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd > $OUT/w_$dt.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/f_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd,scan_idx > $OUT/f_$dt.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/w_$dt -o k -- python $R/tools/bench_kernels.py --iters 3 --dtype $dt --batch 1536 --only scan_bwd,scan_idx > $OUT/w_$dt.log 2>&1
 done
 python - <<PY
 import sqlite3, glob, json
