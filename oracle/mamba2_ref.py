@@ -1,9 +1,14 @@
 """fp64 CPU restatement of the Mamba-2 operator used by `--use-mamba2`.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for the operator arithmetic: the reference calls `mamba_split_conv1d_scan_combined` from the
-absent wheel mamba-ssm==2.0.4 (block/mamba2.py:17-21; call sites :392-450).  This restates its published
-semantics sequentially: split [z | xBC | dt], causal conv + SiLU on xBC, per-head scalar-decay
-state-space recurrence (one chunk, since chunk_size 256 >= L), gated RMSNorm, out_proj.
+The reference calls `mamba_split_conv1d_scan_combined` from the absent wheel mamba-ssm==2.0.4 (block/mamba2.py:17-21; call
+sites :392-450).  This restates its published semantics sequentially: split [z | xBC | dt], causal conv + SiLU on
+xBC, per-head scalar-decay state-space recurrence (one chunk, since chunk_size 256 >= L), gated RMSNorm, out_proj.
+
+PARITY PINNED (round 2) by the reference's own pure-PyTorch `Mamba2.step()` (block/mamba2.py:715-775) run token by token in
+fp64 (G10): conv, recurrence, D skip and the SiLU(z) gate are reference-held end to end (cases m2.a / m2.b, rmsnorm=False);
+with rmsnorm=True (m2.c / m2.d) the reference calls the absent wheel's RMSNormGated, for which the generator supplies the
+documented forward (norm_before_gate=False: rmsnorm(y * silu(z)) * weight).  tests/test_golden_cpu.py holds
+`mamba_split_conv1d_scan_combined_ref` to G10 at <= 1e-9.
 """
 from __future__ import annotations
 

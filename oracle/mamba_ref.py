@@ -1,10 +1,15 @@
 """fp64/fp32 CPU restatement of the Mamba-1 operator used by DiffMa.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for the operator arithmetic: the reference calls `mamba_inner_fn` from the un-vendored
-wheel mamba-ssm==2.0.4 (block/mamba.py:11, call sites :346-348) and holds no vectors for it.  This
-file restates that package's published reference recurrences (`selective_scan_ref`,
-`causal_conv1d_ref`, and the composition in `mamba_inner_ref`; mathematics in SURVEY.md A.1) with
-plain sequential loops -- deliberately different in structure from the HIP kernels.
+The reference calls `mamba_inner_fn` from the un-vendored wheel mamba-ssm==2.0.4 (block/mamba.py:11, call sites :346-348).
+This file restates that package's published reference recurrences (`selective_scan_ref`, `causal_conv1d_ref`, and the
+composition in `mamba_inner_ref`; mathematics in SURVEY.md A.1) with plain sequential loops -- deliberately different in
+structure from the HIP kernels.
+
+PARITY PINNED (round 2): the reference itself holds this arithmetic in pure PyTorch -- `Mamba.step()`, block/mamba.py:405-448
+(conv step, x_proj, dt_proj, softplus, exp(dt*A) state update, C.h, D skip, SiLU(z) gate, out_proj), reached when the absent
+wheels' decode kernels are None.  tools/gen_golden.py runs it token by token in fp64 (G10, tests/golden/g10_reference_step.npz;
+no function of this file takes part) and tests/test_golden_cpu.py::test_oracle_mamba_inner_matches_reference_step holds
+`mamba_inner_ref` / `selective_scan_ref` (incl. the final state) to it at <= 1e-9.
 
 Layout convention here is the REFERENCE's: channel-major (B, D, L) like block/mamba.py:333-337.
 """
