@@ -64,8 +64,12 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 
 // IDX : z_row_index / out_row_index tables are used (both non-null)
 // CKPT: the state is written to p.ckpt after every FWD_CKE = 4 steps (fp32, or bf16 pairs for bf16 I/O)
-template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF, bool ASH = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : ((sizeof(T) == 4 && N <= 16) ? DM_FWD_F32_WAVES : 1)))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+// ACC : DM_FLAG_ACC_DIRS -- blockIdx.y is the batch element; the wave walks its ndir directions one after the other and
+//       ACCUMULATES their outputs into ONE token-order buffer out[batch][row][d] (direction 0 stores, the others read-add-store
+//       through out_row_index): the CrossMerge sum happens here and the separate 4-tensor merge pass disappears.
+template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF, bool ASH = false, bool ACC = false>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ACC ? ((sizeof(T) == 2 && N <= 16) ? 3 : 1) : ((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : ((sizeof(T) == 4 && N <= 16) ? DM_FWD_F32_WAVES : 1))))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+    static_assert(!ACC || IDX, "accumulating the directions needs the row-index tables");
     static_assert(N % 2 == 0, "d_state must be even");
     static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
     constexpr int NP = N / 2;
@@ -81,19 +85,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     // exactly the same values to exactly the same addresses as that lane (a benign duplicate store), which
     // keeps every store unpredicated.
     const int d = (d_raw < p.dim) ? d_raw : p.dim - 1;
-    const int s = blockIdx.y;
     const int L = p.seqlen;
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
+    const int grp = (blockIdx.x * WAVE) / (p.dim / p.ngroups);
+    const int ndirs = ACC ? p.nseq / bpd : 1;
+  for (int dd = 0; dd < ndirs; ++dd) {
+    const int s = ACC ? dd * bpd + (int)blockIdx.y : (int)blockIdx.y;
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
-    const int grp = (blockIdx.x * WAVE) / (p.dim / p.ngroups);
+    const bool accum = ACC && dd > 0;                                // wave-uniform: this direction adds to what is already there
+    if (accum) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous direction's stores have reached L2
 
     // SRD addressing: one descriptor per tensor based at this sequence, the lane's channel offset in ONE
     // VGPR, wave-uniform row offsets in SGPRs (dm_common.h).
     const rsrc_t r_u = make_rsrc((const T*)p.u + (int64_t)s * p.u_ss);
     const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
     const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
-    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss);
+    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)(ACC ? sb : s) * p.o_ss);
     const int vo = d * ES;
     const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_o = (int)p.o_sl * ES;
     const int lane = threadIdx.x;
@@ -143,13 +151,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     };
 
     // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
-    float ru[PF], rd[PF], rz[PF];
+    // (ACC: the value already in the output row rides in the same ring; the loads bypass the vector L1 -- aux sc0|sc1 -- because
+    //  the row was written by this very wave while it walked the previous direction)
+    auto ld_old = [&](int l) -> float {
+        if constexpr (ACC) {
+            if (!accum) return 0.0f;
+            if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_o, vo, oidx[l] * sl_o, 17));
+            else {
+                const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r_o, vo, oidx[l] * sl_o, 17);
+                T t;
+                __builtin_memcpy(&t, &b, 2);
+                return io<T>::ld(&t);
+            }
+        } else {
+            return 0.0f;
+        }
+    };
+    float ru[PF], rd[PF], rz[PF], ro[ACC ? PF : 1];
 #pragma unroll
     for (int j = 0; j < PF; ++j) {
         const int l = (j < L) ? j : L - 1;
         ru[j] = bio<T>::ld(r_u, vo, l * sl_u);
         rd[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
         if (HAS_Z) rz[j] = bio<T>::ld(r_z, vo, (IDX ? zidx[l] : l) * sl_z);
+        if (ACC) ro[j] = ld_old(l);
     }
     auto fetch_bc = [&](int l0, float(&v)[PER]) {        // rows l0 .. l0+PF-1 (clamped), this lane's piece
         int l = l0 + bc_step;
@@ -172,8 +197,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     // One block of PF steps: request the NEXT block's rows into (nu, nd, nz, nbc), then run the PF steps on
     // the rows that are already here.  The caller alternates two register sets (ping-pong), so the ring
     // never needs a register-to-register copy.
-    auto run_block = [&](int l0, const float(&cu)[PF], const float(&cd)[PF], const float(&cz)[PF], float(&nu)[PF],
-                         float(&nd)[PF], float(&nz)[PF]) {
+    auto run_block = [&](int l0, const float(&cu)[PF], const float(&cd)[PF], const float(&cz)[PF], const float(&co)[ACC ? PF : 1],
+                         float(&nu)[PF], float(&nd)[PF], float(&nz)[PF], float(&no)[ACC ? PF : 1]) {
         float nbc[PER];
         fetch_bc(l0 + PF, nbc);
 #pragma unroll
@@ -183,6 +208,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
             nu[j] = bio<T>::ld(r_u, vo, l * sl_u);
             nd[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
             if (HAS_Z) nz[j] = bio<T>::ld(r_z, vo, (IDX ? zidx[l] : l) * sl_z);
+            if (ACC) no[j] = ld_old(l);
         }
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
@@ -193,7 +219,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
                 Bc[k] = bc_lds[buf][j][k];
                 Cc[k] = bc_lds[buf][j][N + k];
             }
-            const float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
+            float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, cu[j], cd[j], HAS_Z ? cz[j] : 0.0f, Dv, bias);
+            if (ACC) y += co[j];
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
             if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l0 + j + 1);      // l0 is a multiple of PF
         }
@@ -202,19 +229,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     };
 
     const int Lfull = (L / PF) * PF;
-    float su[PF], sd[PF], sz[PF];             // second register set of the ring
+    float su[PF], sd[PF], sz[PF], so[ACC ? PF : 1];             // second register set of the ring
     int l0 = 0;
     for (; l0 + 2 * PF <= Lfull; l0 += 2 * PF) {
-        run_block(l0, ru, rd, rz, su, sd, sz);
-        run_block(l0 + PF, su, sd, sz, ru, rd, rz);
+        run_block(l0, ru, rd, rz, ro, su, sd, sz, so);
+        run_block(l0 + PF, su, sd, sz, so, ru, rd, rz, ro);
     }
     if (l0 < Lfull) {                          // odd number of full blocks
-        run_block(l0, ru, rd, rz, su, sd, sz);
+        run_block(l0, ru, rd, rz, ro, su, sd, sz, so);
 #pragma unroll
         for (int j = 0; j < PF; ++j) {
             ru[j] = su[j];
             rd[j] = sd[j];
             if (HAS_Z) rz[j] = sz[j];
+            if (ACC) ro[j] = so[j];
         }
     }
     // tail (< PF steps); its rows are already in the ring
@@ -228,7 +256,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
                 Bc[k] = bc_lds[buf][j][k];
                 Cc[k] = bc_lds[buf][j][N + k];
             }
-            const float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
+            float y = scan_step<N, HAS_Z, SOFTPLUS, ASH>(h, A2, Bc, Cc, ru[j], rd[j], HAS_Z ? rz[j] : 0.0f, Dv, bias);
+            if (ACC) y += ro[j];
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
             if (CKPT && (j + 1) % FWD_CKE == 0) store_ckpt(l + 1);
         }
@@ -244,6 +273,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
             ls[(int64_t)(2 * k + 1) * p.dim] = h[k].y;
         }
     }
+  }   // directions (one trip unless ACC)
 }
 
 constexpr int SCAN_PF = 8;
@@ -252,6 +282,14 @@ static_assert(SCAN_PF % FWD_CKE == 0, "checkpoints fall on fixed positions of a 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_fwd3(const dm_scan_fwd_args& a, hipStream_t st, dim3 grid) {
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
+    if constexpr (N == 16 && HAS_Z && IDX) {          // directions accumulated in the kernel: the model's call pattern only
+        if ((a.flags & DM_FLAG_ACC_DIRS) && sp && !(a.flags & DM_FLAG_A_SHARED)) {
+            const dim3 g2(grid.x, a.batch_per_dir);
+            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, true, true, SCAN_PF, false, true>), g2, dim3(WAVE), 0, st, a);
+            else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, false, true, SCAN_PF, false, true>), g2, dim3(WAVE), 0, st, a);
+            return;
+        }
+    }
     if constexpr (N == 16 && HAS_Z && IDX) {          // the one-exp variant is built for the Mamba-2 call pattern only
         if ((a.flags & DM_FLAG_A_SHARED) && sp) {
             if (a.ckpt) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, true, true, SCAN_PF, true>), grid, dim3(WAVE), 0, st, a);

@@ -253,10 +253,13 @@ class _SpiralSSMFn(torch.autograd.Function):
         if need_grad:
             ckpt = hip_ops.alloc_scan_ckpt(ndir * Bsz, L, N, Din, xz.dtype, xz.device)
         oidx = scan_index if out_index is None else out_index
+        acc = merge and hip_ops.scan_acc_dirs_ok(xc, ndir, N)      # the 3-way CrossMerge sum done by the scan itself
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
-                                out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt)                   # token order
+                                out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt, acc_dirs=acc)     # token order
         ctx.merge = merge
         ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx)
+        if acc:
+            return ydir                                            # [B, L, Din], already merged
         if not merge:
             return ydir.view(ndir, Bsz, L, Din)
         return hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din)) if ndir > 1 else ydir

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 12
+#define DM_ABI_VERSION 13
 
 typedef enum {
     DM_OK = 0,
@@ -53,8 +53,13 @@ enum {
                                    Mamba-2: the gated RMSNorm sits between the scan and the merge) instead of
                                    [batch_per_dir][row][d] shared by the directions  */
     DM_FLAG_SCAN_SEQUENTIAL = 16, /* scan fwd / bwd: take the sequential-in-time kernel whatever the launch size          */
-    DM_FLAG_SCAN_CHUNKED = 32   /* scan fwd / bwd: take the chunk-parallel (two-pass) kernel where it is instantiated;
+    DM_FLAG_SCAN_CHUNKED = 32,  /* scan fwd / bwd: take the chunk-parallel (two-pass) kernel where it is instantiated;
                                    by default the library chooses by launch size (small launches are latency-bound)       */
+    DM_FLAG_ACC_DIRS = 64       /* scan fwd with row indices: `out` is ONE buffer [batch_per_dir][row][d] (o_ss = its batch
+                                   stride) into which the ndir directions of a batch element are accumulated in order
+                                   (CrossMerge, block/mamba.py:59-69, folded into the scan: out[b][idx[dir][l]] += y).
+                                   Needs d_state 16, z, both index tables, DM_FLAG_DELTA_SOFTPLUS, no DM_FLAG_A_SHARED; the
+                                   sequential kernel is taken whatever the launch size.                                   */
 };
 
 /* ------------------------------------------------------------------------------------------------

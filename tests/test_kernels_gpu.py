@@ -153,6 +153,47 @@ def test_scan_fwd_row_index_and_checkpoints(gpu):
             torch.testing.assert_close(ckpt[s, c].cpu().double().T, hl[0], rtol=1e-4, atol=1e-5 * max(1.0, hl.abs().max().item()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,ndir,with_ckpt", [(2, 196, 256, 3, True), (3, 49, 128, 3, False), (2, 37, 200, 4, True), (1, 13, 64, 2, False)])
+def test_scan_fwd_accumulates_directions(gpu, dtype, Bsz, L, Dm, ndir, with_ckpt):
+    """DM_FLAG_ACC_DIRS: one wave walks the ndir directions of a batch element and accumulates them into ONE token-order buffer
+    (CrossMerge folded into the scan) -- against the oracle scan per direction scattered and summed in fp64, and the
+    checkpoints of every direction still equal the unmerged launch's."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import selective_scan_ref
+
+    N = 16
+    S = Bsz * ndir
+    host, d = _inputs(S, L, Dm, N, dtype, seed=L + Dm + ndir, dev=gpu, with_z=False)
+    g = torch.Generator().manual_seed(5)
+    zsrc = torch.randn(Bsz, L, Dm, generator=g).to(dtype)
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    operms = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+    ck1 = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_() if with_ckpt else None
+    ck2 = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_() if with_ckpt else None
+    kw = dict(z_row_index=perms.to(gpu), out_row_index=operms.to(gpu), batch_per_dir=Bsz)
+    merged = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zsrc.to(gpu), d["bias"], True, ckpt=ck1, acc_dirs=True, **kw)
+    plain = hip_ops.scan_fwd(d["u"], d["delta"], d["A"], d["B"], d["C"], d["D"], zsrc.to(gpu), d["bias"], True, ckpt=ck2,
+                             variant="sequential", **kw)
+    torch.cuda.synchronize()
+    assert merged.shape == (Bsz, L, Dm)
+    if with_ckpt:
+        assert torch.equal(ck1, ck2)
+    ref = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+    for s_ in range(S):
+        k, b = divmod(s_, Bsz)
+        cm = lambda t: t[s_:s_ + 1].float().permute(0, 2, 1).double()
+        zz = zsrc[b][perms[k].long()].float().T[None].double()
+        y = selective_scan_ref(cm(host["u"]), cm(host["delta"]), host["A"].double(), cm(host["B"]), cm(host["C"]),
+                               host["D"].double(), z=zz, delta_bias=host["bias"].double(), delta_softplus=True)[0].T      # [L, Dm] scan order
+        ref[b] = ref[b].index_add(0, operms[k].long(), y)
+    rtol, atol = TOL[dtype]
+    torch.testing.assert_close(merged.float().cpu().double(), ref, rtol=rtol, atol=atol * ndir * max(1.0, ref.abs().max().item()))
+    # and against the separate merge pass over the unmerged launch (same values up to the rounding of the running sum)
+    tm = hip_ops.token_merge(plain.view(ndir, Bsz, L, Dm))
+    torch.testing.assert_close(merged.float(), tm.float(), rtol=rtol, atol=atol * max(1.0, ref.abs().max().item()))
+
+
 @pytest.mark.parametrize("N", [8, 32, 64])
 def test_scan_fwd_other_dstate(gpu, N):
     from diffma_amd import hip_ops
