@@ -25,7 +25,7 @@ DM_FLAG_DOUT_PER_SEQ = 4
 DM_FLAG_A_SHARED = 8
 DM_FLAG_SCAN_SEQUENTIAL = 16
 DM_FLAG_SCAN_CHUNKED = 32
-DM_FLAG_ACC_DIRS = 64
+DM_FLAG_OUT_ACCUMULATE = 64
 
 _SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 

@@ -38,10 +38,10 @@ extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream)
     if ((a.z_row_index == nullptr) != (a.out_row_index == nullptr)) {
         set_error("dm_selective_scan_fwd: z_row_index and out_row_index must both be set or both be NULL"); return DM_ERR_ARG;
     }
-    if (a.flags & DM_FLAG_ACC_DIRS) {
+    if (a.flags & DM_FLAG_OUT_ACCUMULATE) {
         if (!a.z || !a.z_row_index || a.dstate != 16 || !(a.flags & DM_FLAG_DELTA_SOFTPLUS) || (a.flags & DM_FLAG_A_SHARED) ||
-            a.batch_per_dir <= 0 || a.last_state) {
-            set_error("dm_selective_scan_fwd: DM_FLAG_ACC_DIRS needs z, row indices, d_state 16, delta softplus, batch_per_dir, no last_state / A_SHARED");
+            (a.batch_per_dir > 0 && a.batch_per_dir != a.nseq) || a.last_state) {
+            set_error("dm_selective_scan_fwd: DM_FLAG_OUT_ACCUMULATE needs z, row indices, d_state 16, delta softplus, ONE direction per launch, no last_state / A_SHARED");
             return DM_ERR_ARG;
         }
     }

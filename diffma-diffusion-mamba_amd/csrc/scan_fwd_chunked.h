@@ -172,7 +172,7 @@ constexpr int CHUNKED_NW = 14, CHUNKED_LC = 14;          // 14 waves x 14 steps:
 static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
     static const int env = [] { const char* e = getenv("DM_SCAN_CHUNKED"); return e ? atoi(e) : -1; }();   // 0 / 1: developer override
     const int forced = (a.flags & DM_FLAG_SCAN_SEQUENTIAL) ? 0 : ((a.flags & DM_FLAG_SCAN_CHUNKED) ? 1 : env);
-    if (forced == 0 || (a.flags & DM_FLAG_ACC_DIRS)) return false;
+    if (forced == 0 || (a.flags & DM_FLAG_OUT_ACCUMULATE)) return false;
     const int64_t waves = (int64_t)a.nseq * ((a.dim + WAVE - 1) / WAVE);
     if (a.ckpt && !(a.z && a.z_row_index && (a.flags & DM_FLAG_DELTA_SOFTPLUS))) return false;   // checkpoints: model call pattern only
     return !a.last_state && a.dstate == 16 && (waves <= 512 || forced == 1) && a.seqlen > 4 * CHUNKED_NW &&

@@ -64,12 +64,13 @@ __device__ __forceinline__ float scan_step(f32x2 (&h)[N / 2], const f32x2 (&A2)[
 
 // IDX : z_row_index / out_row_index tables are used (both non-null)
 // CKPT: the state is written to p.ckpt after every FWD_CKE = 4 steps (fp32, or bf16 pairs for bf16 I/O)
-// ACC : DM_FLAG_ACC_DIRS -- blockIdx.y is the batch element; the wave walks its ndir directions one after the other and
-//       ACCUMULATES their outputs into ONE token-order buffer out[batch][row][d] (direction 0 stores, the others read-add-store
-//       through out_row_index): the CrossMerge sum happens here and the separate 4-tensor merge pass disappears.
+// ACC : DM_FLAG_OUT_ACCUMULATE -- the launch ADDS its outputs to what `out` already holds (read-add-store through
+//       out_row_index) instead of storing them.  The host walks the directions of the CrossMerge with one launch each into ONE
+//       token-order buffer (direction 0 stores, the others accumulate): the merge sum happens here and the separate
+//       4-tensor merge pass disappears.  One direction per launch, so no two waves ever touch the same output element.
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool CKPT, bool SOFTPLUS, int PF, bool ASH = false, bool ACC = false>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ACC ? ((sizeof(T) == 2 && N <= 16) ? 3 : 1) : ((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? 4 : ((sizeof(T) == 4 && N <= 16) ? DM_FWD_F32_WAVES : 1))))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
-    static_assert(!ACC || IDX, "accumulating the directions needs the row-index tables");
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) == 2 && sizeof(TBC) == 2 && N <= 16) ? (ACC ? 3 : 4) : ((sizeof(T) == 4 && N <= 16) ? DM_FWD_F32_WAVES : 1)))) void scan_fwd_kernel(const dm_scan_fwd_args p) {
+    static_assert(!ACC || IDX, "accumulating launches are built for the model's call pattern (row-index tables)");
     static_assert(N % 2 == 0, "d_state must be even");
     static_assert(PF == 8, "the B/C staging below maps 8 steps onto the 64 lanes");
     constexpr int NP = N / 2;
@@ -88,20 +89,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ACC ? ((size
     const int L = p.seqlen;
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
     const int grp = (blockIdx.x * WAVE) / (p.dim / p.ngroups);
-    const int ndirs = ACC ? p.nseq / bpd : 1;
-  for (int dd = 0; dd < ndirs; ++dd) {
-    const int s = ACC ? dd * bpd + (int)blockIdx.y : (int)blockIdx.y;
+    const int s = blockIdx.y;
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
-    const bool accum = ACC && dd > 0;                                // wave-uniform: this direction adds to what is already there
-    if (accum) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the previous direction's stores have reached L2
 
     // SRD addressing: one descriptor per tensor based at this sequence, the lane's channel offset in ONE
     // VGPR, wave-uniform row offsets in SGPRs (dm_common.h).
     const rsrc_t r_u = make_rsrc((const T*)p.u + (int64_t)s * p.u_ss);
     const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
     const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
-    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)(ACC ? sb : s) * p.o_ss);
+    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss);
     const int vo = d * ES;
     const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_o = (int)p.o_sl * ES;
     const int lane = threadIdx.x;
@@ -151,21 +148,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ACC ? ((size
     };
 
     // ---- register prefetch ring: rows of block b+1 are requested before block b is computed ----
-    // (ACC: the value already in the output row rides in the same ring; the loads bypass the vector L1 -- aux sc0|sc1 -- because
-    //  the row was written by this very wave while it walked the previous direction)
+    // (ACC: the value already in the output row rides in the same ring)
     auto ld_old = [&](int l) -> float {
-        if constexpr (ACC) {
-            if (!accum) return 0.0f;
-            if constexpr (sizeof(T) == 4) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r_o, vo, oidx[l] * sl_o, 17));
-            else {
-                const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r_o, vo, oidx[l] * sl_o, 17);
-                T t;
-                __builtin_memcpy(&t, &b, 2);
-                return io<T>::ld(&t);
-            }
-        } else {
-            return 0.0f;
-        }
+        if constexpr (ACC) return bio<T>::ld(r_o, vo, oidx[l] * sl_o);
+        else return 0.0f;
     };
     float ru[PF], rd[PF], rz[PF], ro[ACC ? PF : 1];
 #pragma unroll
@@ -273,7 +259,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ACC ? ((size
             ls[(int64_t)(2 * k + 1) * p.dim] = h[k].y;
         }
     }
-  }   // directions (one trip unless ACC)
 }
 
 constexpr int SCAN_PF = 8;
@@ -282,11 +267,10 @@ static_assert(SCAN_PF % FWD_CKE == 0, "checkpoints fall on fixed positions of a 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_fwd3(const dm_scan_fwd_args& a, hipStream_t st, dim3 grid) {
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
-    if constexpr (N == 16 && HAS_Z && IDX) {          // directions accumulated in the kernel: the model's call pattern only
-        if ((a.flags & DM_FLAG_ACC_DIRS) && sp && !(a.flags & DM_FLAG_A_SHARED)) {
-            const dim3 g2(grid.x, a.batch_per_dir);
-            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, true, true, SCAN_PF, false, true>), g2, dim3(WAVE), 0, st, a);
-            else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, false, true, SCAN_PF, false, true>), g2, dim3(WAVE), 0, st, a);
+    if constexpr (N == 16 && HAS_Z && IDX) {          // accumulating launch: the model's call pattern only
+        if ((a.flags & DM_FLAG_OUT_ACCUMULATE) && sp && !(a.flags & DM_FLAG_A_SHARED)) {
+            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, true, true, SCAN_PF, false, true>), grid, dim3(WAVE), 0, st, a);
+            else hipLaunchKernelGGL((scan_fwd_kernel<T, TBC, N, true, true, false, true, SCAN_PF, false, true>), grid, dim3(WAVE), 0, st, a);
             return;
         }
     }

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_ACC_DIRS, DM_FLAG_A_SHARED, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -161,13 +161,32 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
              ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False, variant=None, acc_dirs=False):
     """u, delta: [S, L, Dm] token-major (last stride 1).  Bm, Cm: [S, L, G*N] views (state stride 1).
     z: [S or S/ndir, Lz, Dm] or None.  A: [Dm, N] fp32.  Returns out [S, L, Dm] (allocated if None).
-    acc_dirs: the ndir directions of a batch element are accumulated by the kernel into ONE token-order buffer
-    [batch_per_dir, L, Dm] (DM_FLAG_ACC_DIRS: CrossMerge folded into the scan); that buffer is what is returned."""
+    acc_dirs: the ndir directions are accumulated into ONE token-order buffer [batch_per_dir, L, Dm], which is returned: one
+    launch per direction, the first stores, the others add (DM_FLAG_OUT_ACCUMULATE) -- CrossMerge folded into the scan."""
     _require_gpu(u, delta, A, Bm, Cm, z)
     S, L, Dm = u.shape
     N = A.shape[1]
+    if acc_dirs:
+        Bd = batch_per_dir
+        ndir = S // Bd
+        if out is None:
+            out = torch.empty((Bd, L, Dm), dtype=u.dtype, device=u.device)
+        for k in range(ndir):
+            sl = slice(k * Bd, (k + 1) * Bd)
+            _scan_fwd_launch(u[sl], delta[sl], A, Bm[sl], Cm[sl], D, z, delta_bias, delta_softplus, z_row_index[k:k + 1],
+                             out_row_index[k:k + 1], 0, out, None if ckpt is None else ckpt[sl], ckpt_every, None, ngroups, False,
+                             "sequential", k > 0)
+        return out
     if out is None:
-        out = torch.empty((batch_per_dir if acc_dirs else S, L, Dm), dtype=u.dtype, device=u.device)
+        out = torch.empty((S, L, Dm), dtype=u.dtype, device=u.device)
+    return _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_row_index, out_row_index, batch_per_dir, out, ckpt,
+                            ckpt_every, last_state, ngroups, a_shared, variant, False)
+
+
+def _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_row_index, out_row_index, batch_per_dir, out, ckpt,
+                     ckpt_every, last_state, ngroups, a_shared, variant, accumulate):
+    S, L, Dm = u.shape
+    N = A.shape[1]
     A = _f32c(A)
     D = _f32c(D)
     delta_bias = _f32c(delta_bias)
@@ -178,7 +197,7 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.io_dtype = dtype_code(u)
     a.bc_dtype = dtype_code(Bm)
     a.flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_A_SHARED if a_shared else 0) | _variant_flag(variant)
-               | (DM_FLAG_ACC_DIRS if acc_dirs else 0))
+               | (DM_FLAG_OUT_ACCUMULATE if accumulate else 0))
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
@@ -195,8 +214,8 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     a.B_sg = a.C_sg = N
     nbytes = scan_fwd_algorithmic_bytes(S, Dm, L, N, u.element_size(), Bm.element_size(), z is not None)
     design = nbytes
-    if acc_dirs:                                 # ndir - 1 read-add-store passes over the merged buffer instead of ndir stores
-        design += (2 * (S // batch_per_dir - 1) + 1 - S // batch_per_dir) * batch_per_dir * Dm * L * u.element_size()
+    if accumulate:                               # the running sum is read back once per accumulating launch
+        design += S * Dm * L * u.element_size()
     if ckpt is not None:
         design += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * Dm * 4     # slots 1.. + slot 0 (the final state)
     _launch("dm_selective_scan_fwd", a, u, nbytes, design)
@@ -313,9 +332,12 @@ def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out
 XPROJ_FUSED_MIN_SEQS = 512
 
 
-# Directions accumulated inside the forward scan (DM_FLAG_ACC_DIRS) instead of a separate token_merge pass: pays once the launch
-# is large enough for the sequential kernel anyway (the chunk-parallel forward for small launches has no accumulating form).
-ACC_DIRS_MIN_WAVES = 1024
+# Directions accumulated by the forward scan (DM_FLAG_OUT_ACCUMULATE, one launch per direction) instead of a separate token_merge
+# pass (the chunk-parallel forward for small launches has no accumulating form).
+# Measured (MI355X, DiffMa-L/2, batch 512): the three per-direction launches cost 45.2 ms per step against 39.6 ms for the one
+# 3-direction launch (tails and prologues of three smaller grids; the accumulating kernel needs 139 VGPRs), the merge pass
+# they replace 4.9 ms: a wash (277.6 vs 277.2 ms per step).  Off by default; DIFFMA_ACC_DIRS=1 turns it on.
+ACC_DIRS_MIN_WAVES = 1024 if os.environ.get("DIFFMA_ACC_DIRS") == "1" else None
 
 
 def scan_acc_dirs_ok(u, ndir, N, a_shared=False):

@@ -55,10 +55,11 @@ enum {
     DM_FLAG_SCAN_SEQUENTIAL = 16, /* scan fwd / bwd: take the sequential-in-time kernel whatever the launch size          */
     DM_FLAG_SCAN_CHUNKED = 32,  /* scan fwd / bwd: take the chunk-parallel (two-pass) kernel where it is instantiated;
                                    by default the library chooses by launch size (small launches are latency-bound)       */
-    DM_FLAG_ACC_DIRS = 64       /* scan fwd with row indices: `out` is ONE buffer [batch_per_dir][row][d] (o_ss = its batch
-                                   stride) into which the ndir directions of a batch element are accumulated in order
-                                   (CrossMerge, block/mamba.py:59-69, folded into the scan: out[b][idx[dir][l]] += y).
-                                   Needs d_state 16, z, both index tables, DM_FLAG_DELTA_SOFTPLUS, no DM_FLAG_A_SHARED; the
+    DM_FLAG_OUT_ACCUMULATE = 64 /* scan fwd with row indices: out[s][out_row_index[l]] += y (read-add-store) instead of = y.
+                                   The caller walks the directions of the CrossMerge (block/mamba.py:59-69) with one launch
+                                   each into ONE token-order buffer: direction 0 stores, the others accumulate, and the
+                                   separate merge pass disappears.  One direction per launch (batch_per_dir = 0 or nseq),
+                                   d_state 16, z, both index tables, DM_FLAG_DELTA_SOFTPLUS, no DM_FLAG_A_SHARED; the
                                    sequential kernel is taken whatever the launch size.                                   */
 };
 
