@@ -270,9 +270,10 @@ namespace dm {
 //   wave w owns the output channels [w * dim/8, (w+1) * dim/8) of the product (dim/128 column tiles of 16);
 //   thread t owns channels 2t, 2t+1 of the convolution (32-bit accesses), like K3x.
 template <typename T, typename TW, int W, bool SILU, int D, bool IDX>
-__global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_conv_xproj_bwd_args p) {
+__global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_conv_xproj_bwd_args p) {
     constexpr int NTW = D / 128;                                      // column tiles (16 channels) per wave
     constexpr int ROWP = D + 4;                                       // fp32 LDS row stride: rows 4g + r of a D-fragment fall on disjoint banks
+    constexpr int KP = 64;                                            // projection width (nproj): two MFMA K steps
     static_assert(D % 128 == 0 && D <= 2 * XP_THREADS, "dim must be a multiple of 128 and at most 1024");
     __shared__ __attribute__((aligned(16))) float ptile[XP_TM * ROWP];
 
@@ -283,7 +284,6 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
-    const int P = p.nproj;                                            // multiple of 8, <= 64
     const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;
     const bool act = (D == 2 * XP_THREADS) ? true : (2 * tid < D);
     const int c = act ? 2 * tid : 0;
@@ -292,10 +292,22 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_
     const rsrc_t r_du = make_rsrc((const T*)p.du + (int64_t)s * p.du_ss);
     const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)s * p.dx_ss);
     const rsrc_t r_xd = make_rsrc((const T*)p.dxdbl + (int64_t)s * L * p.xd_sr);
-    const rsrc_t r_wt = make_rsrc(p.wxt);                             // [dim][nproj]
+    const rsrc_t r_wt = make_rsrc(p.wxt);                             // [dim][64]
     const int vo = c * ES;
     const int sl_x = (int)p.x_sl * ES, sl_du = (int)p.du_sl * ES, sl_dx = (int)p.dx_sl * ES, sr_xd = (int)p.xd_sr * ES;
-    const bool k_on[2] = {8 * g < P, 32 + 8 * g < P};                 // this lane's 8-wide K slices inside the projection width
+
+    // x_proj.weight^T rows of this wave's channels as B-fragments, resident for the whole sequence:
+    // B[k][j] = Wx[k][ch] = wxt[ch][k]; lane (g, j) holds wxt[(wave*NTW + n)*16 + j][32 kk + 8g .. +7]
+    xp_u32x4 bfrag[NTW][2];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+        const int ch = (wave * NTW + n) * 16 + ij;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_wt, (ch * KP + 32 * kk + 8 * g) * ES, 0, 0);
+            bfrag[n][kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
+        }
+    }
 
     float w[W][2], bias[2], dw[W][2], db[2], gwin[W - 1][2];          // gwin[k] = g[l + 1 + k] of the rows already processed (later in time)
 #pragma unroll
@@ -312,13 +324,13 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_
     }
 
     const int ntile = (L + XP_TM - 1) / XP_TM;
-    // x rows l0-(W-1) .. l0+15 of a tile (xr[0 .. W-2] = halo); rows before the sequence start are zero
+    // x rows l0-(W-1) .. l0+15 of a tile (xr[0 .. W-2] = halo); rows before the sequence start are masked at use
     constexpr int NXR = XP_TM + W - 1;
     auto load_x = [&](int l0, uint32_t(&xr)[NXR]) {
 #pragma unroll
         for (int j = 0; j < NXR; ++j) {
             const int lr = l0 - (W - 1) + j;
-            int l = lr < 0 ? 0 : (lr < L ? lr : L - 1);
+            const int l = lr < 0 ? 0 : (lr < L ? lr : L - 1);
             const int r = IDX ? idx[l] : l;
             xr[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo, r * sl_x, 0);
         }
@@ -331,38 +343,37 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_
             dur[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo, l * sl_du, 0);
         }
     };
-    uint32_t xr[NXR], dur[XP_TM];
+    // dx_dbl rows of a tile as A-fragments: lane (g, i) holds dx_dbl[l0 + i][32 kk + 8g .. +7]; rows past L read row L-1 and are zeroed
+    auto load_a = [&](int l0, xp_u32x4(&af)[2]) {
+        const int lr = l0 + ij;
+        const int l = lr < L ? lr : L - 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, l * sr_xd + (32 * kk + 8 * g) * ES, 0, 0);
+            af[kk] = (lr < L) ? (xp_u32x4){q[0], q[1], q[2], q[3]} : (xp_u32x4){0u, 0u, 0u, 0u};
+        }
+    };
+    uint32_t xr[NXR], xn[NXR], dur[XP_TM];
+    xp_u32x4 afrag[2], anext[2];
+    load_a((ntile - 1) * XP_TM, afrag);
+    load_x((ntile - 1) * XP_TM, xr);
     load_du_half((ntile - 1) * XP_TM, 0, dur);
     load_du_half((ntile - 1) * XP_TM, 1, dur);
 
     for (int t = ntile - 1; t >= 0; --t) {
         const int l0 = t * XP_TM;
-        // ---- product tile on the matrix pipe: ptile[i][n] = sum_k dx_dbl[l0 + i][k] * Wx[k][n]  (rows past L are zero) ----
-        xp_u32x4 afrag[2];
+        // ---- product tile on the matrix pipe: ptile[i][n] = sum_k dx_dbl[l0 + i][k] * Wx[k][n]; no memory waits: every operand is resident ----
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            afrag[kk] = (xp_u32x4){0u, 0u, 0u, 0u};
-            if (k_on[kk] && l0 + ij < L) {
-                const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES, 0, 0);
-                afrag[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
-            }
-        }
-        load_x(l0, xr);                                                // consumed after the barrier: in flight during the product
-#pragma unroll 2
         for (int n = 0; n < NTW; ++n) {
-            const int ch = (wave * NTW + n) * 16 + ij;                 // B[k][j] = Wx[k][ch] = wxt[ch][k]: lane (g, j) reads wxt[ch][32kk + 8g .. +7]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                xp_u32x4 bf = (xp_u32x4){0u, 0u, 0u, 0u};
-                if (k_on[kk]) {
-                    const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_wt, (ch * P + 32 * kk + 8 * g) * ES, 0, 0);
-                    bf = (xp_u32x4){q[0], q[1], q[2], q[3]};
-                }
-                acc = xp_mfma<T>::run(afrag[kk], bf, acc);
-            }
+            acc = xp_mfma<T>::run(afrag[0], bfrag[n][0], acc);
+            acc = xp_mfma<T>::run(afrag[1], bfrag[n][1], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) ptile[(4 * g + r) * ROWP + (wave * NTW + n) * 16 + ij] = acc[r];
+        }
+        if (t > 0) {                                                   // the next (earlier) tile's operands: in flight during this tile's conv phase
+            load_a(l0 - XP_TM, anext);
+            load_x(l0 - XP_TM, xn);
         }
         __syncthreads();
         // ---- conv backward of the tile's rows, last row first ----
@@ -409,6 +420,10 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_bwd_kernel(const dm_
             if (t > 0) load_du_half(l0 - XP_TM, h, dur);
         }
         __syncthreads();                                               // ptile is rewritten by the next tile's product
+#pragma unroll
+        for (int j = 0; j < NXR; ++j) xr[j] = xn[j];
+        afrag[0] = anext[0];
+        afrag[1] = anext[1];
     }
     if (act) {
         float* dwp = p.dw_partial + ((int64_t)s * D + c) * W;
@@ -466,7 +481,7 @@ static int xpb_by_width(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
 
 extern "C" int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype) {
     const bool d_ok = dim == 128 || dim == 256 || dim == 512 || dim == 1024;
-    return (d_ok && nproj >= 8 && nproj <= 64 && nproj % 8 == 0 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;
+    return (d_ok && nproj == 64 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;      // DiffMa: dt_rank 32 + 2 * d_state 16
 }
 
 extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, void* stream) {
@@ -477,7 +492,7 @@ extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, vo
     if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_xproj_bwd: non-positive size"); return DM_ERR_ARG; }
     if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_xproj_bwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
     if (!dm_gather_conv1d_xproj_bwd_supported(a.dim, a.nproj, a.io_dtype)) {
-        set_error("dm_gather_conv1d_xproj_bwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj a multiple of 8 <= 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
+        set_error("dm_gather_conv1d_xproj_bwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj = 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
         return DM_ERR_ARG;
     }
     if (a.x_sd != 1 || a.du_sd != 1 || a.dx_sd != 1) { set_error("dm_gather_conv1d_xproj_bwd: needs token-major tensors"); return DM_ERR_LAYOUT; }

@@ -385,10 +385,10 @@ def gather_conv1d_xproj_fwd(x, weight, bias, wx, *, row_index=None, ndir=1, silu
     return out, xdbl
 
 
-# K4x (conv backward fused with d x~ = du + dx_dbl @ Wx) is parity-green but NOT faster yet (MI355X, D = 1024, 1536 sequences:
-# 837 us against 704 us for the in-place addmm + conv_bwd pair: the conv backward is VALU-bound, ~55 instructions per row and
-# channel pair, and the fused form adds the product tile's LDS round trip and per-tile weight-fragment loads): opt-in.
-XPROJ_FUSED_BWD = os.environ.get("DIFFMA_FUSED_CONV_BWD") == "1"
+# K4x (conv backward fused with d x~ = du + dx_dbl @ Wx; csrc/conv_xproj.hip): measured (MI355X, D = 1024, 1536 sequences)
+# 532 us against 692 us for the in-place addmm + conv_bwd pair -- the product rides on the matrix pipe of a VALU-bound kernel
+# and the 1.2 GB addmm pass disappears.  DIFFMA_FUSED_CONV_BWD=0 turns it off.
+XPROJ_FUSED_BWD = os.environ.get("DIFFMA_FUSED_CONV_BWD", "1") == "1"
 
 
 def conv_xproj_bwd_supported(x, wx, nseq):

@@ -245,7 +245,8 @@ int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype);
  *   dxc[s][l][:] = du[s][l][:] + dxdbl[s*seqlen + l][:] @ wx            (d x~ = dL/du + d x_dbl . x_proj.weight)
  * and is never materialised (the unfused path runs an in-place addmm over [ndir*batch*seqlen][dim] first).  Otherwise as
  * dm_gather_conv1d_bwd: dx in token order per direction; dw_partial [ndir*batch][dim][width], db_partial [ndir*batch][dim]
- * fp32 -- ONE partial row per sequence.  wxt: x_proj.weight TRANSPOSED, [dim][nproj] contiguous, io dtype; nproj % 8 == 0.
+ * fp32 -- ONE partial row per sequence.  wxt: x_proj.weight TRANSPOSED, [dim][nproj] contiguous, io dtype; nproj = 64
+ * (dt_rank 32 + 2 * d_state 16, every DiffMa-* model; other widths take the unfused pair).
  */
 typedef struct {
     int32_t batch, dim, seqlen, width, ndir;

@@ -659,7 +659,7 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
     monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_bwd", counted_b)
     _mixer_case(gpu, torch.bfloat16, 2e-2)          # d_model 64: dim 128, 36 projection rows -> fused forward, unfused backward
     assert calls["n"] >= 1
-    _mixer_case(gpu, torch.bfloat16, 2e-2, d_model=128)   # dim 256, 8 + 32 = 40 projection rows -> both fused kernels
+    _mixer_case(gpu, torch.bfloat16, 2e-2, d_model=512)   # dim 1024, 32 + 32 = 64 projection rows (every DiffMa-*) -> both fused kernels
     assert calls.get("b", 0) >= 1
     g, sd, net, inp = _g5(gpu)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
