@@ -11,9 +11,11 @@
 //   * the recurrence runs sequentially in time inside the lane with the d_state states held in
 //     registers (packed f32x2 -> v_pk_mul/v_pk_fma): per (b,d,l) element that is N exp2 + ~2.5N packed
 //     VALU ops, i.e. the work-optimal count -- a wave-parallel associative (Blelloch) scan of the same
-//     recurrence costs ~2.5x the VALU work and is ALU-bound below the HBM roof.
-//   * B_l / C_l are shared by all channels of a sequence: they are wave-uniform, fetched through the
-//     scalar cache into SGPRs (s_load_dwordx8/16), and used directly as packed-FMA operands.
+//     recurrence costs ~2.5x the VALU work and is ALU-bound below the HBM roof.  Measured (round 2 PMC):
+//     71 VALU instructions per wave-step in the fp32 loop against 67 the mathematics needs, pipe 81 % busy at 1.69 GHz.
+//   * B_l / C_l are shared by all channels of a sequence: the rows of a block of 8 steps are fetched with ONE vector load
+//     per lane, parked as fp32 in a wave-private LDS slab and read back per step as broadcast ds_read_b128 (the scalar-cache
+//     route of the first version cost 32 SALU unpack operations per step for 16-bit B/C).
 //   * latency hiding comes from a register prefetch ring of PF time steps (u, delta, z rows are
 //     requested PF steps before use), not from occupancy: at batch 64 there is one wave per SIMD.
 //   * CrossScan's z gather and CrossMerge's inverse reindex are folded into the row addressing
