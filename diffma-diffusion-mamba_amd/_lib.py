@@ -89,6 +89,7 @@ dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 dm_colsum_args = _make_struct("dm_colsum_args")
+dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
 
 _lib = None
 _lock = threading.Lock()

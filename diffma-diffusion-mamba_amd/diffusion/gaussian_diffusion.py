@@ -11,6 +11,7 @@ Numerics are the reference's: tables float64 -> float32 after indexing, all step
 from __future__ import annotations
 
 import enum
+import os
 import math
 
 import numpy as np
@@ -237,8 +238,31 @@ class GaussianDiffusion:
     def _nonzero_mask(t, ndim):
         return (t != 0).float().view(-1, *([1] * (ndim - 1)))          # no noise at t == 0
 
+    _STEP_ROWS = ("posterior_log_variance_clipped", "log_betas", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_mean_coef1", "posterior_mean_coef2", "alphas_cumprod", "alphas_cumprod_prev")
+    # GPU: the step arithmetic after the model call runs as ONE kernel (csrc/diffusion_step.hip); DIFFMA_FUSED_DIFFUSION_STEP=0: ATen
+    fused_step = os.environ.get("DIFFMA_FUSED_DIFFUSION_STEP", "1") == "1"
+
+    def _fused_step(self, model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, ddim, eta=0.0):
+        """The configuration DiffMa samples with (learned-range variance, epsilon prediction, no guidance) on a ROCm device:
+        model call + dm_diffusion_step.  Returns None when the generic path has to run."""
+        if not (self.fused_step and x.is_cuda and x.dtype == th.float32 and denoised_fn is None and cond_fn is None
+                and self.model_var_type == ModelVarType.LEARNED_RANGE and self.model_mean_type == ModelMeanType.EPSILON):
+            return None
+        from .. import hip_ops
+        out = model(x, t, **(model_kwargs or {}))
+        if isinstance(out, tuple) or out.shape != (x.shape[0], 2 * x.shape[1], *x.shape[2:]) or out.dtype not in (th.float32, th.bfloat16, th.float16):
+            raise ValueError("the denoiser must return one (B, 2C, ...) tensor with learn_sigma (reference gaussian_diffusion.py:286)")
+        noise = th.randn_like(x)
+        rows = [_TABLE_NAMES.index(n) for n in self._STEP_ROWS]
+        sample, x0 = hip_ops.diffusion_step(out, x, t, noise, self._tables(x.device), rows, ddim=ddim, eta=eta, clip=clip_denoised)
+        return {"sample": sample, "pred_xstart": x0}
+
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
         """One ancestral step x_t -> x_{t-1}: {'sample', 'pred_xstart'}."""
+        fused = self._fused_step(model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, ddim=False)
+        if fused is not None:
+            return fused
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
         noise = th.randn_like(x)
         if cond_fn is not None:
@@ -279,6 +303,9 @@ class GaussianDiffusion:
 
     # ---- DDIM ------------------------------------------------------------------------------------------
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        fused = self._fused_step(model, x, t, clip_denoised, denoised_fn, cond_fn, model_kwargs, ddim=True, eta=eta)
+        if fused is not None:
+            return fused
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
         if cond_fn is not None:
             out = self.condition_score(cond_fn, out, x, t, model_kwargs=model_kwargs)

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -622,3 +622,30 @@ def rmsnorm_merge_bwd(y, weight, eps, rstd, dout):
     a.dout_sr, a.dy_ss, a.dy_sr = C, dy.stride(0), C
     _launch("dm_rmsnorm_merge_bwd", a, y, (2 * K + 1) * Bsz * L * C * y.element_size())
     return dy, part.sum(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# Sampler step after the denoiser call (csrc/diffusion_step.hip)
+# ------------------------------------------------------------------------------------------------
+def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0, clip=False):
+    """model_out [B, 2C, ...] (eps | variance logits), x / noise [B, C, ...] fp32, t [B] int64, tables fp32 [K, T];
+    rows: the 8 row numbers (posterior log variance, log betas, sqrt(1/abar), sqrt(1/abar - 1), coef1, coef2, abar, abar_prev).
+    Returns (sample, pred_xstart), both fp32 like x: one kernel instead of ~25 elementwise launches."""
+    _require_gpu(model_out, x, t, noise, tables)
+    B, C = x.shape[:2]
+    hw = x[0, 0].numel()
+    model_out = model_out.contiguous()
+    x = x.contiguous()
+    noise = noise.contiguous() if noise is not None else None
+    assert model_out.shape[1] == 2 * C and x.dtype == torch.float32 and t.dtype == torch.int64 and tables.dtype == torch.float32
+    sample, x0 = torch.empty_like(x), torch.empty_like(x)
+    a = dm_diffusion_step_args()
+    a.batch, a.channels, a.hw, a.T = B, C, hw, tables.shape[1]
+    a.mode, a.clip, a.out_dtype = (1 if ddim else 0), (1 if clip else 0), dtype_code(model_out)
+    a.eta = float(eta)
+    (a.row_post_logvar, a.row_log_betas, a.row_sqrt_recip_ac, a.row_sqrt_recipm1_ac, a.row_coef1, a.row_coef2, a.row_ac,
+     a.row_ac_prev) = rows
+    a.model_out, a.x, a.noise, a.t, a.tables = _ptr(model_out), _ptr(x), _ptr(noise), _ptr(t), _ptr(tables)
+    a.sample, a.pred_xstart = _ptr(sample), _ptr(x0)
+    _launch("dm_diffusion_step", a, x, B * C * hw * (2 * model_out.element_size() + 4 * 4))
+    return sample, x0

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 13
+#define DM_ABI_VERSION 14
 
 typedef enum {
     DM_OK = 0,
@@ -378,6 +378,30 @@ typedef struct {
 } dm_colsum_args;
 
 int dm_colsum_f32(const dm_colsum_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * One reverse-diffusion step after the denoiser call, fused (reference diffusion/gaussian_diffusion.py:285-323
+ * p_mean_variance with learned-range variance and epsilon prediction, :232-252 q_posterior_mean_variance, :410-416 p_sample,
+ * :548-598 ddim_sample).  model_out: [batch][2*channels][hw] (eps | variance logits in [-1, 1]), dtype out_dtype; x, noise,
+ * sample, pred_xstart: fp32 [batch][channels][hw] contiguous (noise may be NULL: no noise term; pred_xstart may be NULL).
+ * t: int64 [batch].  tables: fp32 [nrows][T], the caller's per-timestep coefficient rows; the row_* fields name the rows of
+ * log(posterior variance, clipped), log(beta), sqrt(1/abar), sqrt(1/abar - 1), posterior mean coefficients 1 and 2, abar and
+ * abar_prev.  mode 0 = ancestral (DDPM) step, 1 = DDIM step with `eta`.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, channels, hw, T;
+    int32_t mode, clip, out_dtype;
+    float eta;
+    int32_t row_post_logvar, row_log_betas, row_sqrt_recip_ac, row_sqrt_recipm1_ac;
+    int32_t row_coef1, row_coef2, row_ac, row_ac_prev;
+    const void *model_out;
+    const float *x, *noise;
+    const int64_t *t;
+    const float *tables;
+    float *sample, *pred_xstart;
+} dm_diffusion_step_args;
+
+int dm_diffusion_step(const dm_diffusion_step_args *args, void *stream);
 
 /* Library introspection. */
 int dm_abi_version(void);
