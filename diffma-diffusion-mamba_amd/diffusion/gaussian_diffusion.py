@@ -250,13 +250,16 @@ class GaussianDiffusion:
                 and self.model_var_type == ModelVarType.LEARNED_RANGE and self.model_mean_type == ModelMeanType.EPSILON):
             return None
         from .. import hip_ops
-        out = model(x, t, **(model_kwargs or {}))
+        out = self._wrap_model(model)(x, t, **(model_kwargs or {}))        # SpacedDiffusion maps respaced steps to the original ones
         if isinstance(out, tuple) or out.shape != (x.shape[0], 2 * x.shape[1], *x.shape[2:]) or out.dtype not in (th.float32, th.bfloat16, th.float16):
             raise ValueError("the denoiser must return one (B, 2C, ...) tensor with learn_sigma (reference gaussian_diffusion.py:286)")
         noise = th.randn_like(x)
         rows = [_TABLE_NAMES.index(n) for n in self._STEP_ROWS]
         sample, x0 = hip_ops.diffusion_step(out, x, t, noise, self._tables(x.device), rows, ddim=ddim, eta=eta, clip=clip_denoised)
         return {"sample": sample, "pred_xstart": x0}
+
+    def _wrap_model(self, model):
+        return model               # overridden by SpacedDiffusion (timestep translation)
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
         """One ancestral step x_t -> x_{t-1}: {'sample', 'pred_xstart'}."""
