@@ -90,6 +90,7 @@ dm_blend_args = _make_struct("dm_blend_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 dm_colsum_args = _make_struct("dm_colsum_args")
 dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
+dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
 
 _lib = None
 _lock = threading.Lock()
@@ -124,6 +125,8 @@ def load():
                 fn.argtypes = []
             elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
+            elif name == "dm_ssd_fwd_supported":
+                fn.argtypes = [ctypes.c_int] * 4
             elif name == "dm_scan_bwd_launch_group_channels":
                 fn.argtypes = [ctypes.c_int] * 5
             elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported"):

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -649,3 +649,44 @@ def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0,
     a.sample, a.pred_xstart = _ptr(sample), _ptr(x0)
     _launch("dm_diffusion_step", a, x, B * C * hw * (2 * model_out.element_size() + 4 * 4))
     return sample, x0
+
+
+# ------------------------------------------------------------------------------------------------
+# Mamba-2 SSD core on the matrix pipe (csrc/ssd.hip): the no-grad path of --use-mamba2
+# ------------------------------------------------------------------------------------------------
+SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "1") == "1"
+
+
+def ssd_fwd_supported(x, L, headdim, dstate):
+    if not (SSD_MFMA and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    return bool(_lib.load().dm_ssd_fwd_supported(int(L), int(headdim), int(dstate), dtype_code(x)))
+
+
+def ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, *, z_row_index=None, out_row_index=None, batch_per_dir=0, out=None):
+    """x: [S, L, H*64] view, Bm / Cm: [S, L, 16] views (after the conv, per gathered sequence); dt_tok: [B, L, H] and z: [B, L, H*64]
+    in token order; A_h, D_h, dt_bias_h: [H] fp32.  Returns the gated output [S, L, H*64] with step l at row out_row_index[dir][l]."""
+    _require_gpu(x, Bm, Cm, dt_tok, z)
+    S, L, Din = x.shape
+    H = A_h.shape[0]
+    assert Din == H * 64 and Bm.shape[-1] == 16 and x.stride(2) == 1 and Bm.stride(2) == 1 and Cm.stride(2) == 1 and dt_tok.stride(2) == 1
+    if out is None:
+        out = torch.empty((S, L, Din), dtype=x.dtype, device=x.device)
+    A32, D32, b32 = _f32c(A_h), _f32c(D_h), _f32c(dt_bias_h)
+    a = dm_ssd_fwd_args()
+    a.nseq, a.batch_per_dir, a.seqlen, a.nheads, a.headdim, a.dstate = S, batch_per_dir, L, H, 64, 16
+    a.io_dtype, a.flags = dtype_code(x), 0
+    a.x, a.B, a.C, a.dt, a.z = _ptr(x), _ptr(Bm), _ptr(Cm), _ptr(dt_tok), _ptr(z)
+    a.A, a.D, a.dt_bias = _ptr(A32), _ptr(D32), _ptr(b32)
+    a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
+    a.out = _ptr(out)
+    a.x_ss, a.x_sl = x.stride(0), x.stride(1)
+    a.B_ss, a.B_sl = Bm.stride(0), Bm.stride(1)
+    a.C_ss, a.C_sl = Cm.stride(0), Cm.stride(1)
+    a.dt_sb, a.dt_sl = dt_tok.stride(0), dt_tok.stride(1)
+    if z is not None:
+        a.z_ss, a.z_sl = z.stride(0), z.stride(1)
+    a.o_ss, a.o_sl = out.stride(0), out.stride(1)
+    es = x.element_size()
+    _launch("dm_ssd_fwd", a, x, (3 if z is not None else 2) * S * L * Din * es + 2 * S * L * 16 * es)
+    return out

@@ -384,6 +384,14 @@ class _SpiralSSDFn(torch.autograd.Function):
         z, xbc_in, dt_tok = zxbcdt[..., :Din], zxbcdt[..., Din:Din + Cx], zxbcdt[..., Din + Cx:]
         xBC = hip_ops.gather_conv1d_fwd(xbc_in, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)        # [S, L, Cx]
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
+        need_grad = grad_on and any(ctx.needs_input_grad[:7])
+        if not need_grad and hip_ops.ssd_fwd_supported(xBC, L, P, N):
+            # no-grad path on the matrix pipe (csrc/ssd.hip): single-chunk SSD as two dense products per (sequence, head), the
+            # per-head dt read in the kernel through the gather table -- no [S, L, Din] delta tensor, no per-state recurrence
+            ydir = hip_ops.ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, z_row_index=scan_index, out_row_index=scan_index,
+                                   batch_per_dir=Bsz)
+            out, _ = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+            return out
         # dt is produced per token and per head: gather its rows per direction, broadcast head -> channels
         idx64 = scan_index.long()
         dt_g = torch.stack([dt_tok[:, idx64[k]] for k in range(ndir)])                                            # [ndir, B, L, H]
@@ -391,7 +399,6 @@ class _SpiralSSDFn(torch.autograd.Function):
         A = A_h.float().repeat_interleave(P)[:, None].expand(Din, N).contiguous()
         Dskip = D_h.float().repeat_interleave(P)
         dt_bias = dt_bias_h.float().repeat_interleave(P)
-        need_grad = grad_on and any(ctx.needs_input_grad[:7])
         ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, zxbcdt.dtype, zxbcdt.device) if need_grad else None
         ydir = hip_ops.scan_fwd(x, delta, A, Bm, Cm, Dskip, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
                                 batch_per_dir=Bsz, ckpt=ckpt, a_shared=True)     # token order, gated; one decay per head

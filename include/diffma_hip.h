@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 14
+#define DM_ABI_VERSION 15
 
 typedef enum {
     DM_OK = 0,
@@ -378,6 +378,34 @@ typedef struct {
 } dm_colsum_args;
 
 int dm_colsum_f32(const dm_colsum_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Mamba-2 SSD core, single chunk, on the matrix pipe (forward; the no-grad path of --use-mamba2).  Replaces the scan stage of
+ * mamba_split_conv1d_scan_combined (block/mamba2.py:392-410) for chunk_size >= seqlen:
+ *     dt = softplus(dt_raw + dt_bias[h]);  s = A[h] * cumsum(dt);  G = (C B^T) .* exp(s_l - s_i) [i <= l];
+ *     y = (G diag(dt)) x + D[h] x;   out = y * silu(z)
+ * x: [nseq][L][nheads*64] view (the conv output's x columns), B, C: [nseq][L][16] views (16-byte aligned rows), all after the
+ * conv, per gathered sequence; dt_raw: [batch][L][nheads] and z: [batch][L][nheads*64] in TOKEN order, read through z_row_index;
+ * out: [nseq][rows][nheads*64], step l stored at row out_row_index[dir][l].  16-bit I/O, headdim 64, d_state 16,
+ * seqlen <= 224: dm_ssd_fwd_supported() tells; everything else (and training) takes the A-shared scan.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nseq, batch_per_dir, seqlen, nheads, headdim, dstate;
+    int32_t io_dtype, flags;
+    const void *x, *B, *C, *dt, *z;
+    const float *A, *D, *dt_bias;       /* [nheads] fp32 (D, dt_bias may be NULL) */
+    const int32_t *z_row_index, *out_row_index;
+    void *out;
+    int64_t x_ss, x_sl;
+    int64_t B_ss, B_sl;
+    int64_t C_ss, C_sl;
+    int64_t dt_sb, dt_sl;
+    int64_t z_ss, z_sl;
+    int64_t o_ss, o_sl;
+} dm_ssd_fwd_args;
+
+int dm_ssd_fwd(const dm_ssd_fwd_args *args, void *stream);
+int dm_ssd_fwd_supported(int seqlen, int headdim, int dstate, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * One reverse-diffusion step after the denoiser call, fused (reference diffusion/gaussian_diffusion.py:285-323

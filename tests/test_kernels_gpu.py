@@ -617,3 +617,52 @@ def test_colsum_matches_torch(gpu, R, C):
     got = hip_ops.colsum(x.to(gpu)).cpu().double()
     ref = x.double().sum(0)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=1e-5 * max(1.0, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,H,ndir,with_z", [(2, 196, 2, 3, True), (1, 49, 4, 3, True), (2, 16, 1, 1, True), (1, 33, 2, 2, False), (1, 1, 1, 1, True),
+                                                 (1, 224, 1, 1, True)])
+def test_ssd_fwd_mfma_matches_oracle(gpu, dtype, Bsz, L, H, ndir, with_z):
+    """K6 (csrc/ssd.hip): Mamba-2 single-chunk SSD on the matrix pipe against the sequential fp64 restatement
+    (oracle/mamba2_ref.ssd_scan_ref, pinned by G10's Mamba2.step cases) on the ROUNDED inputs, incl. the in-kernel softplus of
+    the per-head dt, the z gather / output scatter tables, ragged L, and against the A-shared scan kernel on the same data."""
+    from diffma_amd import hip_ops
+    from oracle.mamba2_ref import ssd_scan_ref
+    from oracle.mamba_ref import softplus_ref
+
+    P, N = 64, 16
+    Din, S = H * P, Bsz * ndir
+    g = torch.Generator().manual_seed(L * 11 + H + ndir)
+    xBC = torch.randn(S, L, Din + 2 * N, generator=g).to(dtype)
+    dt_tok = (torch.randn(Bsz, L, H, generator=g) * 0.7 - 1.0).to(dtype)
+    ztok = torch.randn(Bsz, L, Din, generator=g).to(dtype) if with_z else None
+    A_h = -(torch.rand(H, generator=g) * 6 + 0.3)
+    D_h, bias_h = torch.randn(H, generator=g), torch.randn(H, generator=g) * 0.5
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    dev = lambda t: None if t is None else t.to(gpu)
+    xb = dev(xBC)
+    out = hip_ops.ssd_fwd(xb[..., :Din], xb[..., Din:Din + N], xb[..., Din + N:], dev(dt_tok), dev(ztok), dev(A_h), dev(D_h), dev(bias_h),
+                          z_row_index=dev(perms), out_row_index=dev(perms), batch_per_dir=Bsz)
+    torch.cuda.synchronize()
+    out = out.float().cpu().double()
+    rtol, atol = TOL[dtype]
+    for s_ in range(S):
+        k, b = divmod(s_, Bsz)
+        idx = perms[k].long()
+        xs = xBC[s_:s_ + 1].float().double()
+        dt = softplus_ref(dt_tok[b][idx].float().double() + bias_h.double())[None]                  # [1, L, H] in scan order
+        y = ssd_scan_ref(xs[..., :Din], dt, A_h.double(), xs[..., Din:Din + N], xs[..., Din + N:], D_h.double(), P)[0]      # [L, Din]
+        if with_z:
+            zz = ztok[b][idx].float().double()
+            y = y * (zz * torch.sigmoid(zz))
+        got = out[s_][idx]                                                                           # row idx[l] holds step l
+        torch.testing.assert_close(got, y, rtol=rtol, atol=atol * max(1.0, y.abs().max().item()), msg=lambda m, s_=s_: f"seq {s_}: {m}")
+    if with_z:                  # the A-shared scan on the same inputs (delta expanded per channel, as _SpiralSSDFn does when training)
+        idx64 = perms.long().to(gpu)
+        dtg = torch.stack([dev(dt_tok)[:, idx64[k]] for k in range(ndir)]).reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din)
+        A = dev(A_h).repeat_interleave(P)[:, None].expand(Din, N).contiguous()
+        ref2 = hip_ops.scan_fwd(xb[..., :Din], dtg.contiguous(), A, xb[..., Din:Din + N], xb[..., Din + N:], dev(D_h).repeat_interleave(P), dev(ztok),
+                                dev(bias_h).repeat_interleave(P), True, z_row_index=dev(perms), out_row_index=dev(perms), batch_per_dir=Bsz,
+                                a_shared=True)
+        sc = max(1.0, ref2.float().abs().max().item())
+        torch.testing.assert_close(out.float(), ref2.float().cpu(), rtol=rtol, atol=atol * sc)
