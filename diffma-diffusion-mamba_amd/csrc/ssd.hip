@@ -121,14 +121,12 @@ __global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
     ssd_u32x4 bfrag[SSD_MAXT];
 #pragma unroll
     for (int it = 0; it < SSD_MAXT; ++it) {
-        bfrag[it] = (ssd_u32x4){0u, 0u, 0u, 0u};
         const int i = SSD_TILE * it + col;
-        if (it < nt_l && i < L) {
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_B, kh * 8 * ES, i * sl_B, 0);
-            const float dti = dt_lds[i];
+        const int ic = i < L ? i : L - 1;
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_B, ic * sl_B + kh * 8 * ES, 0, 0);       // per-lane row: all of it in the VGPR offset
+        const float dti = (i < L) ? dt_lds[ic] : 0.0f;                                                    // rows past the end: zero
 #pragma unroll
-            for (int w = 0; w < 4; ++w) bfrag[it][w] = O::pack(O::lo(q[w]) * dti, O::hi(q[w]) * dti);
-        }
+        for (int w = 0; w < 4; ++w) bfrag[it][w] = O::pack(O::lo(q[w]) * dti, O::hi(q[w]) * dti);
     }
     // X as B-fragments of the output product, keys in accumulator order: slot e of (it, ks) is key 32it + 4kh + 8(2ks + e/4) + e%4
     ssd_u32x4 xfrag[SSD_MAXT][2][2];
@@ -146,7 +144,10 @@ __global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
                     for (int q = 0; q < 2; ++q) {
                         const int e = 2 * e2 + q;
                         const int i = SSD_TILE * it + 4 * kh + 8 * (2 * ks + (e >> 2)) + (e & 3);
-                        pr[q] = (it < nt_l && i < L) ? (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r_x, (32 * nt + col) * ES, i * sl_x, 0) : 0u;
+                        // (rows past the end are clamped and zeroed by a select: no exec-masked branch per load)
+                        const int ic = i < L ? i : L - 1;
+                        const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r_x, ic * sl_x + (32 * nt + col) * ES, 0, 0);
+                        pr[q] = (i < L) ? v : 0u;
                     }
                     w4[e2] = pr[0] | (pr[1] << 16);
                 }
@@ -155,11 +156,10 @@ __global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
 
     for (int lt = 0; lt < nt_l; ++lt) {
         const int lq = SSD_TILE * lt + col;                              // this lane's query in the score tile (a column of G^T)
-        ssd_u32x4 cfrag = (ssd_u32x4){0u, 0u, 0u, 0u};                   // C rows as the B-operand: lane (col l, kh) holds C[l][8kh .. +7]
-        if (lq < L) {
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_C, kh * 8 * ES, lq * sl_C, 0);
-            cfrag = (ssd_u32x4){q[0], q[1], q[2], q[3]};
-        }
+        // C rows as the B-operand: lane (col l, kh) holds C[l][8kh .. +7]; queries past the end produce rows that are never stored
+        const int lqc = lq < L ? lq : L - 1;
+        const auto qc = __builtin_amdgcn_raw_buffer_load_b128(r_C, lqc * sl_C + kh * 8 * ES, 0, 0);
+        const ssd_u32x4 cfrag = {qc[0], qc[1], qc[2], qc[3]};
         const float s2l = s2[lq];
         f32x16 yacc[2];
 #pragma unroll

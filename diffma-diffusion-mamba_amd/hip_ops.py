@@ -654,7 +654,12 @@ def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0,
 # ------------------------------------------------------------------------------------------------
 # Mamba-2 SSD core on the matrix pipe (csrc/ssd.hip): the no-grad path of --use-mamba2
 # ------------------------------------------------------------------------------------------------
-SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "1") == "1"
+# PROTOTYPE, off by default ("keep it only if it beats the A-shared scan"): parity-green against the oracle
+# and the scan, but one wave per (sequence, head) with 112 VGPRs of resident X fragments runs at one wave per SIMD (512
+# registers) -- measured 298 us against 180 us for the A-shared scan at the DiffMa-XL/2 shape (nseq 192, 16 heads), 64 vs 47 us
+# at nseq 3.  DIFFMA_SSD_MFMA=1 routes the no-grad Mamba-2 mixer through it.  What it needs to win: the 64 columns of a head
+# split over two waves (150 VGPRs, 3 waves/SIMD) and the decay factorised per tile pair (exps only on the diagonal tiles).
+SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "0") == "1"
 
 
 def ssd_fwd_supported(x, L, headdim, dstate):

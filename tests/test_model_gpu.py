@@ -677,3 +677,35 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
                                None, None, f(sd10["D"]), delta_bias=f(sd10["dt_proj.bias"]), delta_softplus=True)
             assert rel_l2(o.float().cpu(), want) <= tol, (tag, dtype, rel_l2(o.float().cpu(), want))
     assert calls["n"] > n0
+
+
+def test_mamba2_mixer_inference_on_the_mfma_ssd_prototype(gpu, monkeypatch):
+    """The opt-in matrix-pipe SSD forward (csrc/ssd.hip, DIFFMA_SSD_MFMA=1) inside the Mamba-2 mixer under no_grad + bf16
+    autocast, against the fp64 oracle mixer."""
+    from diffma_amd import hip_ops
+    from diffma_amd.mamba2 import Mamba2
+    from diffma_amd.tools import spiral
+    from oracle.mamba2_ref import mamba2_spiral_forward_ref
+
+    calls = {"n": 0}
+    real = hip_ops.ssd_fwd
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(hip_ops, "SSD_MFMA", True)
+    monkeypatch.setattr(hip_ops, "ssd_fwd", counted)
+    torch.manual_seed(4)
+    n = 14
+    orders, inverses = spiral(n)
+    lists = (orders[6], orders[7], inverses[6], inverses[7])
+    mix = Mamba2(d_model=64, d_state=16, d_conv=4, expand=2, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+                 origina_list_reversal=lists[3]).to(gpu).eval()
+    x = torch.randn(2, n * n, 64, device=gpu)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = mix(x, "spiral").float()
+    assert calls["n"] == 1
+    params = {k: v.detach().cpu().double() for k, v in mix.state_dict().items()}
+    yr = mamba2_spiral_forward_ref(x.cpu().double(), params, lists, headdim=64, dtype=torch.float64)
+    assert rel_l2(y.cpu(), yr) <= 2e-2, rel_l2(y.cpu(), yr)
