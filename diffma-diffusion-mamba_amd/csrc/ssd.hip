@@ -6,11 +6,11 @@
 //     s_l   = A_h * cumsum(dt)_l                          (log-decay, <= 0 and decreasing)
 //     G     = (C B^T) .* exp(s_l - s_i) [i <= l]          [L x L], K = d_state
 //     Y     = (G diag(dt)) X + D_h X                      [L x P], K = L          out = Y * silu(z)
-// One wave64 owns one (sequence, head): 32 x 32 tiles, v_mfma_f32_32x32x16_{bf16,f16}.  The transposed score tile
+// One wave64 owns one (sequence, head, 32-column half): 32 x 32 tiles, v_mfma_f32_32x32x16_{bf16,f16}.  The transposed score tile
 // G^T = (dt .* B)_it C_lt^T is produced with keys as rows and queries as columns, so its accumulator registers ARE the
 // A-operand of the second product (row = query l, K slots = keys in the order 4*(lane>>5) + 8*r4 + r): the decay factor and
 // the causal mask are applied in registers, the tile is rounded to 16 bit and fed straight back -- no LDS round trip, no
-// cross-lane move.  X is held as B-operand fragments in that same key order for the whole sequence (112 VGPRs), so the inner
+// cross-lane move.  X is held as B-operand fragments in that same key order for the whole sequence (56 VGPRs), so the inner
 // loop has no memory operation at all except the broadcast reads of the log-decays from LDS.  z is gathered and the output
 // scattered through the row-index tables exactly like the scan kernels (CrossScan / CrossMerge folded into addressing); the
 // per-head dt is read in the kernel (token order, through the gather table), no [nseq, L, Din] delta tensor exists.
@@ -23,6 +23,7 @@ namespace dm {
 constexpr int SSD_TILE = 32;
 constexpr int SSD_MAXT = 7;                       // L <= 224
 constexpr int SSD_MAXL = SSD_TILE * SSD_MAXT;
+constexpr int SSD_PITCH = 20;                     // dwords per staged tile row (32 channels = 16 dwords, +4 pad)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 ssd_bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,17 +58,29 @@ template <> struct ssd_ops<f16_t> {
     static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(h2, w).y; }
 };
 
+// One wave64 per (sequence, head, 32-column half of the head): 56 VGPRs of X fragments, ~150 registers, 3 waves per SIMD.
+//
+// Decay factorisation.  s2 = log2-domain log-decay prefix sums (decreasing), m_t = s2 just before tile t (m_0 = 0).  For a key
+// tile it strictly before the query tile lt:   exp2(s2_l - s2_i) = alpha_l * delta(lt, it) * gamma_i   with
+//     alpha_l = exp2(s2_l - m_lt),   gamma_i = exp2(m_{it+1} - s2_i),   delta = exp2(m_lt - m_{it+1}),     all three <= 1,
+// so gamma (and dt) is folded into the B rows once, alpha into the C rows once per query tile, and an off-diagonal score tile
+// costs one scalar exp and 16 multiplies.  Only the 7 diagonal tiles of 28 take the element-wise exp (on unscaled operands:
+// there alpha * gamma could underflow while the true factor is O(1)).
 template <typename T>
-__global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
     using O = ssd_ops<T>;
     constexpr int ES = (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) float s2_lds[2][SSD_MAXL + 32];    // log2-domain log-decay (prefix sums, ping-pong)
     __shared__ __attribute__((aligned(16))) float dt_lds[SSD_MAXL];
     __shared__ int zi_lds[SSD_MAXL], oi_lds[SSD_MAXL];
+    // 32-row x 32-channel staging tiles (row pitch 80 B: the two key halves of a fragment read land on disjoint banks): global
+    // traffic is whole 16-byte pieces of a row, the (key, channel) element order of the fragments is produced by LDS reads
+    __shared__ __attribute__((aligned(16))) uint32_t tile_a[SSD_TILE * SSD_PITCH], tile_b[SSD_TILE * SSD_PITCH];
 
     const int lane = threadIdx.x;
     const int col = lane & 31, kh = lane >> 5;
-    const int h = blockIdx.x, s = blockIdx.y;
+    const int trow = lane >> 1, thf = lane & 1;                          // staging role: row of the tile, 16-channel half of it
+    const int h = blockIdx.x >> 1, half = blockIdx.x & 1, s = blockIdx.y;
     const int L = p.seqlen;
     const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
     const int dir = s / bpd;
@@ -76,13 +89,31 @@ __global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
     const int32_t* __restrict__ zidx = p.z_row_index ? p.z_row_index + (int64_t)dir * L : nullptr;
     const int32_t* __restrict__ oidx = p.out_row_index ? p.out_row_index + (int64_t)dir * L : nullptr;
     const float Ah = p.A[h] * LOG2E, Dh = p.D ? p.D[h] : 0.0f, bias = p.dt_bias ? p.dt_bias[h] : 0.0f;
-    const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)s * p.x_ss + (int64_t)h * 64);
+    const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)s * p.x_ss);
     const rsrc_t r_B = make_rsrc((const T*)p.B + (int64_t)s * p.B_ss);
     const rsrc_t r_C = make_rsrc((const T*)p.C + (int64_t)s * p.C_ss);
-    const rsrc_t r_z = make_rsrc(p.z ? (const T*)p.z + (int64_t)sb * p.z_ss + (int64_t)h * 64 : nullptr);
-    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss + (int64_t)h * 64);
+    const rsrc_t r_z = make_rsrc(p.z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
+    const rsrc_t r_o = make_rsrc((T*)p.out + (int64_t)s * p.o_ss);
     const T* __restrict__ dtp = (const T*)p.dt + (int64_t)sb * p.dt_sb + h;
     const int sl_x = (int)p.x_sl * ES, sl_B = (int)p.B_sl * ES, sl_C = (int)p.C_sl * ES, sl_z = (int)p.z_sl * ES, sl_o = (int)p.o_sl * ES;
+
+    // ---- every load that does not depend on the decays goes out first: one HBM round trip covers X, B and the dt gather ------
+    const int cb = (h * 64 + half * 32 + thf * 16) * ES;                 // byte offset of this lane's 16 staged channels in a row
+    ssd_u32x4 xq[SSD_MAXT][2], bq[SSD_MAXT];
+#pragma unroll
+    for (int it = 0; it < SSD_MAXT; ++it) {
+        const int i = SSD_TILE * it + trow;
+        const int ic = i < L ? i : L - 1;                                 // rows past the end: clamped here, zeroed below
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_x, ic * sl_x + cb + 16 * q, 0, 0);
+            xq[it][q] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+        }
+        const int j = SSD_TILE * it + col;
+        const int jc = j < L ? j : L - 1;
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_B, jc * sl_B + kh * 8 * ES, 0, 0);
+        bq[it] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+    }
 
     // ---- per-position scalars: dt = softplus(raw + bias), log-decay prefix sums, row tables -------------------------------
 #pragma unroll
@@ -115,108 +146,176 @@ __global__ __launch_bounds__(64) void ssd_fwd_kernel(const dm_ssd_fwd_args p) {
         cur ^= 1;
     }
     const float* const s2 = s2_lds[cur];
+    auto m_of = [&](int t) -> float { return t == 0 ? 0.0f : s2[SSD_TILE * t - 1]; };   // log-decay just before tile t
 
     // ---- operands resident for the whole sequence ---------------------------------------------------------------------------
-    // (dt .* B) rows as A-fragments of the score product: lane (row i = col, kh) holds dt_i * B[i][8kh .. 8kh+7]
+    // (gamma .* dt .* B) rows as A-fragments of the off-diagonal score products: lane (row i = col, kh) holds 8 states
     ssd_u32x4 bfrag[SSD_MAXT];
 #pragma unroll
     for (int it = 0; it < SSD_MAXT; ++it) {
         const int i = SSD_TILE * it + col;
         const int ic = i < L ? i : L - 1;
-        const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_B, ic * sl_B + kh * 8 * ES, 0, 0);       // per-lane row: all of it in the VGPR offset
-        const float dti = (i < L) ? dt_lds[ic] : 0.0f;                                                    // rows past the end: zero
+        const float sc = (i < L) ? dt_lds[ic] * fast_exp2(m_of(it + 1 < SSD_MAXT ? it + 1 : it) - s2[ic]) : 0.0f;   // (the last tile is never off-diagonal)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) bfrag[it][w] = O::pack(O::lo(q[w]) * dti, O::hi(q[w]) * dti);
+        for (int w = 0; w < 4; ++w) bfrag[it][w] = O::pack(O::lo(bq[it][w]) * sc, O::hi(bq[it][w]) * sc);
     }
     // X as B-fragments of the output product, keys in accumulator order: slot e of (it, ks) is key 32it + 4kh + 8(2ks + e/4) + e%4
-    ssd_u32x4 xfrag[SSD_MAXT][2][2];
+    ssd_u32x4 xfrag[SSD_MAXT][2];
+    {
+        const uint16_t* const ta16 = reinterpret_cast<const uint16_t*>(tile_a);
 #pragma unroll
-    for (int it = 0; it < SSD_MAXT; ++it)
+        for (int it = 0; it < SSD_MAXT; ++it) {
+            const bool live = SSD_TILE * it + trow < L;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int q = 0; q < 2; ++q)
+                *reinterpret_cast<ssd_u32x4*>(&tile_a[trow * SSD_PITCH + thf * 8 + 4 * q]) = live ? xq[it][q] : (ssd_u32x4){0u, 0u, 0u, 0u};
+            __syncthreads();
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int ks = 0; ks < 2; ++ks) {
                 uint32_t w4[4];
 #pragma unroll
                 for (int e2 = 0; e2 < 4; ++e2) {
-                    uint32_t pr[2];
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int e = 2 * e2 + q;
-                        const int i = SSD_TILE * it + 4 * kh + 8 * (2 * ks + (e >> 2)) + (e & 3);
-                        // (rows past the end are clamped and zeroed by a select: no exec-masked branch per load)
-                        const int ic = i < L ? i : L - 1;
-                        const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r_x, ic * sl_x + (32 * nt + col) * ES, 0, 0);
-                        pr[q] = (i < L) ? v : 0u;
-                    }
-                    w4[e2] = pr[0] | (pr[1] << 16);
+                    const int k0 = 4 * kh + 8 * (2 * ks + (e2 >> 1)) + 2 * (e2 & 1);
+                    const uint32_t lo = ta16[k0 * (2 * SSD_PITCH) + col], hi = ta16[(k0 + 1) * (2 * SSD_PITCH) + col];
+                    w4[e2] = lo | (hi << 16);
                 }
-                xfrag[it][ks][nt] = (ssd_u32x4){w4[0], w4[1], w4[2], w4[3]};
+                xfrag[it][ks] = (ssd_u32x4){w4[0], w4[1], w4[2], w4[3]};
             }
+            __syncthreads();
+        }
+    }
 
-    for (int lt = 0; lt < nt_l; ++lt) {
+    // C rows (the B-operand of the score product: lane (col l, kh) holds C[l][8kh .. +7]) and the unscaled B rows of the diagonal
+    // tile are fetched one query tile ahead
+    auto load_cb = [&](int t, ssd_u32x4& c, ssd_u32x4& b) {
+        const int j = SSD_TILE * t + col;
+        const int jc = j < L ? j : L - 1;
+        const auto vc = __builtin_amdgcn_raw_buffer_load_b128(r_C, jc * sl_C + kh * 8 * ES, 0, 0);
+        const auto vb = __builtin_amdgcn_raw_buffer_load_b128(r_B, jc * sl_B + kh * 8 * ES, 0, 0);
+        c = (ssd_u32x4){vc[0], vc[1], vc[2], vc[3]};
+        b = (ssd_u32x4){vb[0], vb[1], vb[2], vb[3]};
+    };
+    ssd_u32x4 cnext, bnext;
+    load_cb(0, cnext, bnext);
+#pragma unroll
+    for (int lt = 0; lt < SSD_MAXT; ++lt) {                              // (fully unrolled: every fragment index is a compile-time constant)
+        if (lt >= nt_l) break;
         const int lq = SSD_TILE * lt + col;                              // this lane's query in the score tile (a column of G^T)
-        // C rows as the B-operand: lane (col l, kh) holds C[l][8kh .. +7]; queries past the end produce rows that are never stored
         const int lqc = lq < L ? lq : L - 1;
-        const auto qc = __builtin_amdgcn_raw_buffer_load_b128(r_C, lqc * sl_C + kh * 8 * ES, 0, 0);
-        const ssd_u32x4 cfrag = {qc[0], qc[1], qc[2], qc[3]};
-        const float s2l = s2[lq];
-        f32x16 yacc[2];
+        const float s2l = s2[lqc], mlt = m_of(lt);
+        const ssd_u32x4 craw = cnext, qb = bnext;                         // raw C for the diagonal tile, alpha-scaled for the others
+        const ssd_u32x4 qc = craw;
+        if (lt + 1 < SSD_MAXT) load_cb(lt + 1, cnext, bnext);
+        ssd_u32x4 zq[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};                // the gate tile of this query tile, in flight under the products
+        const int lrow = SSD_TILE * lt + trow;
+        const int lrc = lrow < L ? lrow : L - 1;
+        if (p.z) {
+            const int zr = zi_lds[lrc];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+            for (int q = 0; q < 2; ++q) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zr * sl_z + cb + 16 * q, 0, 0);
+                zq[q] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+        const float alpha = fast_exp2(s2l - mlt);
+        ssd_u32x4 cfrag;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) yacc[nt][r] = 0.0f;
+        for (int w = 0; w < 4; ++w) cfrag[w] = O::pack(O::lo(qc[w]) * alpha, O::hi(qc[w]) * alpha);
+        f32x16 yacc;
 #pragma unroll
-        for (int it = 0; it < SSD_MAXT; ++it) {
-            if (it <= lt) {                                               // wave-uniform
+        for (int r = 0; r < 16; ++r) yacc[r] = 0.0f;
+        // ---- key tiles strictly before the query tile: factorised decay ----
+#pragma unroll
+        for (int it = 0; it < SSD_MAXT - 1; ++it) {
+            if (it < lt) {                                                // wave-uniform
                 f32x16 g;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) g[r] = 0.0f;
-                g = O::mfma(bfrag[it], cfrag, g);                         // G^T tile: rows = keys 32it + 4kh + 8r4 + r, columns = queries
+                g = O::mfma(bfrag[it], cfrag, g);                         // rows = keys 32it + 4kh + 8r4 + r, columns = queries
+                const float delta = fast_exp2(mlt - m_of(it + 1));
                 uint32_t wp[8];
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 si = *reinterpret_cast<const f32x4*>(&s2[SSD_TILE * it + 4 * kh + 8 * r4]);
-                    float wv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = SSD_TILE * it + 4 * kh + 8 * r4 + r;
-                        const float e = fast_exp2(s2l - si[r]);
-                        wv[r] = (it < lt || i <= lq) ? g[4 * r4 + r] * e : 0.0f;      // causal mask only bites on the diagonal tile
-                    }
-                    wp[2 * r4] = O::pack(wv[0], wv[1]);
-                    wp[2 * r4 + 1] = O::pack(wv[2], wv[3]);
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const f32x2 gs = (f32x2){g[2 * r2], g[2 * r2 + 1]} * (f32x2){delta, delta};        // v_pk_mul_f32
+                    wp[r2] = O::pack(gs.x, gs.y);
                 }
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) yacc[nt] = O::mfma(wf, xfrag[it][ks][nt], yacc[nt]);
+                    yacc = O::mfma(wf, xfrag[it][ks], yacc);
                 }
             }
         }
-        // ---- epilogue of the query tile: + D x, gate, scatter.  yacc[nt][4 r4 + r] = Y[32lt + 4kh + 8 r4 + r][32nt + col] ----
+        // ---- the diagonal tile: element-wise decay and causal mask on unscaled operands ----
+        {
+            const int i = SSD_TILE * lt + col;
+            const int ic = i < L ? i : L - 1;
+            const float dti = (i < L) ? dt_lds[ic] : 0.0f;
+            ssd_u32x4 bd;
 #pragma unroll
-        for (int it = 0; it < SSD_MAXT; ++it) {                           // (compile-time index into xfrag)
-            if (it == lt) {
+            for (int w = 0; w < 4; ++w) bd[w] = O::pack(O::lo(qb[w]) * dti, O::hi(qb[w]) * dti);
+            f32x16 g;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
+            for (int r = 0; r < 16; ++r) g[r] = 0.0f;
+            g = O::mfma(bd, craw, g);
+            uint32_t wp[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int l = SSD_TILE * lt + 4 * kh + 8 * r4 + r;
-                        if (l < L) {
-                            const int zr = zi_lds[l], orow = oi_lds[l];
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 si = *reinterpret_cast<const f32x4*>(&s2[SSD_TILE * lt + 4 * kh + 8 * r4]);
+                float wv[4];
 #pragma unroll
-                            for (int nt = 0; nt < 2; ++nt) {
-                                const int e = 4 * (r4 & 1) + r;
-                                const uint32_t xw = xfrag[it][r4 >> 1][nt][e >> 1];
-                                const float xv = (e & 1) ? O::hi(xw) : O::lo(xw);
-                                float y = yacc[nt][4 * r4 + r] + Dh * xv;
-                                if (p.z) y *= silu_f(bio<T>::ld(r_z, zr * sl_z + (32 * nt + col) * ES, 0));
-                                bio<T>::st(r_o, orow * sl_o + (32 * nt + col) * ES, 0, y);
-                            }
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const int ik = SSD_TILE * lt + 4 * kh + 8 * r4 + r;
+                    wv[r] = (ik <= lq) ? g[4 * r4 + r] * fast_exp2(s2l - si[r]) : 0.0f;
+                }
+                wp[2 * r4] = O::pack(wv[0], wv[1]);
+                wp[2 * r4 + 1] = O::pack(wv[2], wv[3]);
+            }
+#pragma unroll
+            for (int it = 0; it < SSD_MAXT; ++it) {                       // (compile-time index into xfrag)
+                if (it == lt) {
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
+                        yacc = O::mfma(wf, xfrag[it][ks], yacc);
                     }
+                }
+            }
+        }
+        // ---- epilogue of the query tile: + D x, gate, scatter.  yacc[4 r4 + r] = Y[32lt + 4kh + 8 r4 + r][this lane's channel] ----
+        if (p.z) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) *reinterpret_cast<ssd_u32x4*>(&tile_a[trow * SSD_PITCH + thf * 8 + 4 * q]) = zq[q];
+        }
+        __syncthreads();
+        {
+            const uint16_t* const ta16 = reinterpret_cast<const uint16_t*>(tile_a);
+            uint16_t* const tb16 = reinterpret_cast<uint16_t*>(tile_b);
+#pragma unroll
+            for (int it = 0; it < SSD_MAXT; ++it) {                       // (compile-time index into xfrag)
+                if (it == lt) {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = 4 * kh + 8 * r4 + r;
+                            const int e = 4 * (r4 & 1) + r;
+                            const uint32_t xw = xfrag[it][r4 >> 1][e >> 1];
+                            const float xv = (e & 1) ? O::hi(xw) : O::lo(xw);
+                            float y = yacc[4 * r4 + r] + Dh * xv;
+                            if (p.z) y *= silu_f(O::lo((uint32_t)ta16[row * (2 * SSD_PITCH) + col]));
+                            tb16[row * (2 * SSD_PITCH) + col] = (uint16_t)(O::pack(y, 0.0f) & 0xffffu);
+                        }
+                }
+            }
+        }
+        __syncthreads();
+        if (lrow < L) {
+            const int orow = oi_lds[lrow];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const ssd_u32x4 v = *reinterpret_cast<const ssd_u32x4*>(&tile_b[trow * SSD_PITCH + thf * 8 + 4 * q]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, r_o, orow * sl_o + cb + 16 * q, 0, 0);
             }
         }
     }
@@ -244,7 +343,11 @@ extern "C" int dm_ssd_fwd(const dm_ssd_fwd_args* args, void* stream) {
     if (((uintptr_t)a.B & 15) || ((uintptr_t)a.C & 15) || (a.B_ss & 7) || (a.B_sl & 7) || (a.C_ss & 7) || (a.C_sl & 7)) {
         set_error("dm_ssd_fwd: B / C rows must be 16-byte aligned"); return DM_ERR_LAYOUT;
     }
-    dim3 grid(a.nheads, a.nseq), block(WAVE);
+    if (((uintptr_t)a.x & 15) || ((uintptr_t)a.out & 15) || (a.x_ss & 7) || (a.x_sl & 7) || (a.o_ss & 7) || (a.o_sl & 7) ||
+        (a.z && (((uintptr_t)a.z & 15) || (a.z_ss & 7) || (a.z_sl & 7)))) {
+        set_error("dm_ssd_fwd: x / z / out rows must be 16-byte aligned (tiles move as 16-byte pieces)"); return DM_ERR_LAYOUT;
+    }
+    dim3 grid(a.nheads * 2, a.nseq), block(WAVE);          // two 32-column halves per head
     hipStream_t st = (hipStream_t)stream;
     if (a.io_dtype == DM_BF16) hipLaunchKernelGGL((ssd_fwd_kernel<bf16_t>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((ssd_fwd_kernel<f16_t>), grid, block, 0, st, a);

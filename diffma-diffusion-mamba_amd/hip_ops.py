@@ -654,17 +654,21 @@ def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0,
 # ------------------------------------------------------------------------------------------------
 # Mamba-2 SSD core on the matrix pipe (csrc/ssd.hip): the no-grad path of --use-mamba2
 # ------------------------------------------------------------------------------------------------
-# PROTOTYPE, off by default ("keep it only if it beats the A-shared scan"): parity-green against the oracle
-# and the scan, but one wave per (sequence, head) with 112 VGPRs of resident X fragments runs at one wave per SIMD (512
-# registers) -- measured 298 us against 180 us for the A-shared scan at the DiffMa-XL/2 shape (nseq 192, 16 heads), 64 vs 47 us
-# at nseq 3.  DIFFMA_SSD_MFMA=1 routes the no-grad Mamba-2 mixer through it.  What it needs to win: the 64 columns of a head
-# split over two waves (150 VGPRs, 3 waves/SIMD) and the decay factorised per tile pair (exps only on the diagonal tiles).
-SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "0") == "1"
+# On by default for 16-bit inference ("keep it only if it beats the A-shared scan" -- it does, DiffMa-XL/2
+# mixer shape, 16 heads x 64, L 196: 26 vs 68 us at nseq 24, 101 vs 183 us at nseq 192, 415 vs 513 us at nseq 768, tools/bench_ssd.py).
+# One wave per (sequence, head, 32-column half); the decay is factorised per tile pair so only the diagonal tiles take
+# element-wise exps; X / z / out tiles move as 16-byte row pieces through LDS.  DIFFMA_SSD_MFMA=0 returns the no-grad Mamba-2
+# mixer to the A-shared scan.  Training (and fp32 I/O) stay on the scan: the backward twin is not written yet.
+SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "1") == "1"
 
 
-def ssd_fwd_supported(x, L, headdim, dstate):
+def ssd_fwd_supported(x, L, headdim, dstate, views=()):
+    """views: the x / B / C / z views the launch would get -- their rows must start on 16-byte boundaries (tiles move as 16-byte pieces)."""
     if not (SSD_MFMA and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
         return False
+    for v in views:
+        if v is not None and (v.data_ptr() % 16 or v.stride(-1) != 1 or any(st % 8 for st in v.stride()[:-1])):
+            return False
     return bool(_lib.load().dm_ssd_fwd_supported(int(L), int(headdim), int(dstate), dtype_code(x)))
 
 

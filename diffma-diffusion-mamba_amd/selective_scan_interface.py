@@ -385,7 +385,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         xBC = hip_ops.gather_conv1d_fwd(xbc_in, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)        # [S, L, Cx]
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         need_grad = grad_on and any(ctx.needs_input_grad[:7])
-        if not need_grad and hip_ops.ssd_fwd_supported(xBC, L, P, N):
+        if not need_grad and hip_ops.ssd_fwd_supported(xBC, L, P, N, views=(x, Bm, Cm, z)):
             # no-grad path on the matrix pipe (csrc/ssd.hip): single-chunk SSD as two dense products per (sequence, head), the
             # per-head dt read in the kernel through the gather table -- no [S, L, Din] delta tensor, no per-state recurrence
             ydir = hip_ops.ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, z_row_index=scan_index, out_row_index=scan_index,

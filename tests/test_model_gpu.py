@@ -680,7 +680,7 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
 
 
 def test_mamba2_mixer_inference_on_the_mfma_ssd_prototype(gpu, monkeypatch):
-    """The opt-in matrix-pipe SSD forward (csrc/ssd.hip, DIFFMA_SSD_MFMA=1) inside the Mamba-2 mixer under no_grad + bf16
+    """The matrix-pipe SSD forward (csrc/ssd.hip; DIFFMA_SSD_MFMA, on by default) inside the Mamba-2 mixer under no_grad + bf16
     autocast, against the fp64 oracle mixer."""
     from diffma_amd import hip_ops
     from diffma_amd.mamba2 import Mamba2

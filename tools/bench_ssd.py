@@ -10,7 +10,7 @@ Din = H * P
 dt_ = torch.bfloat16
 
 
-def timeit(fn, iters=30):
+def timeit(fn, iters=int(os.environ.get("SSD_ITERS", "30"))):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
