@@ -91,6 +91,7 @@ dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 dm_colsum_args = _make_struct("dm_colsum_args")
 dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
 dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
+dm_ssd_bwd_args = _make_struct("dm_ssd_bwd_args")
 
 _lib = None
 _lock = threading.Lock()
@@ -125,7 +126,7 @@ def load():
                 fn.argtypes = []
             elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
-            elif name == "dm_ssd_fwd_supported":
+            elif name in ("dm_ssd_fwd_supported", "dm_ssd_bwd_supported"):
                 fn.argtypes = [ctypes.c_int] * 4
             elif name == "dm_scan_bwd_launch_group_channels":
                 fn.argtypes = [ctypes.c_int] * 5

@@ -17,6 +17,7 @@
 // 16-bit I/O only (the score tile is rounded to the I/O dtype); fp32 I/O and the training path stay on the A-shared scan.
 #include <type_traits>
 #include "dm_common.h"
+#include "ssd_common.h"
 
 namespace dm {
 
@@ -24,39 +25,6 @@ constexpr int SSD_TILE = 32;
 constexpr int SSD_MAXT = 7;                       // L <= 224
 constexpr int SSD_MAXL = SSD_TILE * SSD_MAXT;
 constexpr int SSD_PITCH = 20;                     // dwords per staged tile row (32 channels = 16 dwords, +4 pad)
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 ssd_bf16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 ssd_f16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t ssd_u32x4 __attribute__((ext_vector_type(4)));
-
-template <typename T> struct ssd_ops;
-template <> struct ssd_ops<bf16_t> {
-    static __device__ __forceinline__ f32x16 mfma(const ssd_u32x4& a, const ssd_u32x4& b, const f32x16& c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssd_bf16x8, a), __builtin_bit_cast(ssd_bf16x8, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
-    }
-    static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
-    static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-};
-template <> struct ssd_ops<f16_t> {
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ f32x16 mfma(const ssd_u32x4& a, const ssd_u32x4& b, const f32x16& c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(ssd_f16x8, a), __builtin_bit_cast(ssd_f16x8, b), c, 0, 0, 0);
-    }
-    static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
-        h2 v;
-        v.x = (_Float16)lo;
-        v.y = (_Float16)hi;
-        return __builtin_bit_cast(uint32_t, v);
-    }
-    static __device__ __forceinline__ float lo(uint32_t w) { return (float)__builtin_bit_cast(h2, w).x; }
-    static __device__ __forceinline__ float hi(uint32_t w) { return (float)__builtin_bit_cast(h2, w).y; }
-};
 
 // One wave64 per (sequence, head, 32-column half of the head): 56 VGPRs of X fragments, ~150 registers, 3 waves per SIMD.
 //

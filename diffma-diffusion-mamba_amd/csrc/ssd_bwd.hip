@@ -1,0 +1,521 @@
+// K6b  dm_ssd_bwd -- backward of the Mamba-2 single-chunk SSD core on the matrix pipe (twin of ssd.hip).
+//
+// Operator (reference call block/mamba2.py:392-410 under autograd), per (sequence, head), L <= 196, P = 64, N = 16:
+//     dt = softplus(raw + bias),  s_l = A * cumsum(dt)_l,  M[l,i] = exp(s_l - s_i) [i <= l],  G = C B^T,  W = G .* M .* dt_i
+//     Y = W X,   u = Y + D X,   out = u .* silu(z)
+// Gradients, with gY = dout .* silu(z) and R = gY X^T (K = headdim):
+//     dz = dout .* u .* silu'(z)                        dX = W^T gY + D gY                 dD = sum gY .* X
+//     dG = R .* M .* dt_i:   dC = dG B,  dB = dG^T C    (partial per head; B and C are shared by the heads)
+//     V  = R .* G .* M:      ds_l = sum_i V[l,i] dt_i - dt_l sum_q V[q,l];   d dt_i = sum_l V[l,i] + A * sum_{l >= i} ds_l
+//     dA = sum_l ds_l cumsum(dt)_l;    d raw = d dt * sigmoid(raw + bias)
+// Nothing is saved by the forward.  One 512-thread workgroup per (sequence, head) holds X, gY (row-major AND transposed), B, C
+// (both ways) in 123 KB of LDS and walks the 28 causal 32 x 32 tile pairs twice, concurrently:
+//   * waves 0-3, "T" orientation (score tile with keys as rows, queries as columns): its accumulator registers are the
+//     A-operand of  Y += W X  and  dC += dG B  -- they own query tiles {6}, {5,0}, {4,1}, {3,2} (7 pairs each);
+//   * waves 4-7, "N" orientation (queries as rows, keys as columns): accumulators are the A-operand of  dX += W^T gY  and
+//     dB += dG^T C  -- they own key tiles {0}, {1,6}, {2,5}, {3,4}.
+// Each orientation computes its own G (1 MFMA) and R (4 MFMAs, K = 64) per pair, applies the decay (factorised per tile pair as in
+// the forward: alpha_l * delta(lt,it) * gamma_i off the diagonal, element-wise exp + causal mask on the 7 diagonal tiles), feeds
+// the rounded tiles straight back (no LDS round trip), and accumulates the row sums (T) / column sums (N) of V that d dt and dA
+// need.  22 MFMAs and ~100 VALU per pair and orientation.  Tile epilogues turn 8 rows at a time through a 2 KB staging tile so
+// every global access is a 16-byte piece of a row.  The final d dt / dA reverse cumulative sum runs on the whole workgroup.
+#include "dm_common.h"
+#include "ssd_common.h"
+
+namespace dm {
+
+typedef uint32_t ssd_u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SB_MAXL = 196;                      // rows held in LDS
+constexpr int SB_TILE = 32, SB_MAXT = 7;
+constexpr int SB_TAB = SB_TILE * SB_MAXT;         // 224 table slots (tile-rounded)
+constexpr int SB_TPITCH = SB_MAXL * 2;            // bytes per row of a transposed array: 98 dwords = 2 mod 32 banks
+constexpr int SB_THREADS = 512;
+constexpr int SB_STG = 68;                        // dwords per staging-tile row (64 + 4)
+
+// LDS map (byte offsets)
+constexpr int SB_XS = 0;                          // X   [196][64]  16-byte chunks XOR-swizzled by (row & 7)
+constexpr int SB_GS = SB_XS + SB_MAXL * 128;      // gY  [196][64]  same layout
+constexpr int SB_XT = SB_GS + SB_MAXL * 128;      // X^T [64][196]
+constexpr int SB_GT = SB_XT + 64 * SB_TPITCH;     // gY^T[64][196]
+constexpr int SB_BS = SB_GT + 64 * SB_TPITCH;     // B   [196][16]
+constexpr int SB_CS = SB_BS + SB_MAXL * 32;       // C   [196][16]
+constexpr int SB_BT = SB_CS + SB_MAXL * 32;       // B^T [16][196]
+constexpr int SB_CT = SB_BT + 16 * SB_TPITCH;     // C^T [16][196]
+constexpr int SB_TABS = SB_CT + 16 * SB_TPITCH;   // fp32 tables [T_NTAB][224]
+enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_TMP0, T_TMP1, T_NTAB };
+constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // int tables: z rows, dout rows
+constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 4;         // 8 waves x [8][SB_STG] fp32
+constexpr int SB_RED = SB_STAGE + 8 * 8 * SB_STG * 4;     // block-reduction scratch [2][8] fp32
+constexpr int SB_LDS_BYTES = SB_RED + 64;
+static_assert(SB_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+__device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS writes visible to its other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// 8 consecutive columns (chunk) of a row of the swizzled [196][64] arrays, as an MFMA operand fragment; rows past the end read 0
+__device__ __forceinline__ ssd_u32x4 row_frag(const uint8_t* base, int row, int chunk) {
+    const int rc = row < SB_MAXL ? row : SB_MAXL - 1;
+    const ssd_u32x4 v = *reinterpret_cast<const ssd_u32x4*>(base + rc * 128 + ((chunk ^ (rc & 7)) << 4));
+    return row < SB_MAXL ? v : (ssd_u32x4){0u, 0u, 0u, 0u};
+}
+// 8 states of a B / C row
+__device__ __forceinline__ ssd_u32x4 bc_frag(const uint8_t* base, int row, int kh) {
+    const int rc = row < SB_MAXL ? row : SB_MAXL - 1;
+    const ssd_u32x4 v = *reinterpret_cast<const ssd_u32x4*>(base + rc * 32 + kh * 16);
+    return row < SB_MAXL ? v : (ssd_u32x4){0u, 0u, 0u, 0u};
+}
+// B-operand of a product whose K index runs over sequence positions in ACCUMULATOR order: slots 0-3 = positions k0..k0+3, slots
+// 4-7 = k0+8..k0+11 of row `prow` of a transposed array (k0 = 32 tile + 4 kh + 16 ks); positions past the end read 0
+__device__ __forceinline__ ssd_u32x4 t_frag(const uint8_t* base, int prow, int k0, bool live = true) {
+    const int a = k0 < SB_MAXL ? k0 : 0, b = k0 + 8 < SB_MAXL ? k0 + 8 : 0;
+    const ssd_u32x2 lo = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + a * 2);
+    const ssd_u32x2 hi = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + b * 2);
+    const bool la = live && k0 < SB_MAXL, lb = live && k0 + 8 < SB_MAXL;
+    return (ssd_u32x4){la ? lo.x : 0u, la ? lo.y : 0u, lb ? hi.x : 0u, lb ? hi.y : 0u};
+}
+
+template <typename T>
+__global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_args p) {
+    using O = ssd_ops<T>;
+    constexpr int ES = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    float* const tab = reinterpret_cast<float*>(lds + SB_TABS);
+    float* const DT = tab + T_DT * SB_TAB;
+    float* const CUM = tab + T_CUM * SB_TAB;
+    float* const S2 = tab + T_S2 * SB_TAB;
+    float* const ALPHA = tab + T_ALPHA * SB_TAB;
+    float* const GAM = tab + T_GAM * SB_TAB;
+    float* const GDT = tab + T_GDT * SB_TAB;
+    float* const SIG = tab + T_SIG * SB_TAB;
+    float* const RS = tab + T_RS * SB_TAB;
+    float* const CSV = tab + T_CS * SB_TAB;
+    int* const zi = reinterpret_cast<int*>(lds + SB_IDX);
+    int* const oi = zi + SB_TAB;
+    float* const red = reinterpret_cast<float*>(lds + SB_RED);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, s = blockIdx.y;
+    const int L = p.seqlen, H = p.nheads;
+    const int bpd = (p.batch_per_dir > 0) ? p.batch_per_dir : p.nseq;
+    const int dir = s / bpd;
+    const int sb = s - dir * bpd;
+    const int nt_l = (L + SB_TILE - 1) / SB_TILE;
+    const int LR = (SB_TILE * nt_l < SB_MAXL) ? SB_TILE * nt_l : SB_MAXL;          // LDS rows to fill (zeros past L)
+    const int32_t* __restrict__ zidx = p.z_row_index ? p.z_row_index + (int64_t)dir * L : nullptr;
+    const int32_t* __restrict__ oidx = p.out_row_index ? p.out_row_index + (int64_t)dir * L : nullptr;
+    const float Ah = p.A[h], a2 = Ah * LOG2E, Dh = p.D ? p.D[h] : 0.0f, bias = p.dt_bias ? p.dt_bias[h] : 0.0f;
+    const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)s * p.x_ss);
+    const rsrc_t r_B = make_rsrc((const T*)p.B + (int64_t)s * p.B_ss);
+    const rsrc_t r_C = make_rsrc((const T*)p.C + (int64_t)s * p.C_ss);
+    const rsrc_t r_z = make_rsrc(p.z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
+    const rsrc_t r_do = make_rsrc((const T*)p.dout + (int64_t)s * p.do_ss);
+    const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)s * p.dx_ss);
+    const rsrc_t r_dz = make_rsrc(p.dz ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);
+    const T* __restrict__ dtp = (const T*)p.dt + (int64_t)sb * p.dt_sb + h;
+    const int sl_x = (int)p.x_sl * ES, sl_B = (int)p.B_sl * ES, sl_C = (int)p.C_sl * ES, sl_z = (int)p.z_sl * ES;
+    const int sl_do = (int)p.do_sl * ES, sl_dx = (int)p.dx_sl * ES, sl_dz = (int)p.dz_sl * ES;
+    const int hb = h * 64 * ES;                                                   // byte offset of the head's columns in a row
+    float* const dbc_part = p.dBC_part + ((int64_t)s * H + h) * L * 32;
+
+    // ---- phase 0: per-position scalars -----------------------------------------------------------------------------------
+    if (tid < SB_TAB) {
+        float dtv = 0.0f, sg = 0.0f;
+        int zr = 0, orow = 0;
+        if (tid < L) {
+            zr = zidx ? zidx[tid] : tid;
+            orow = oidx ? oidx[tid] : tid;
+            const float raw = io<T>::ld(dtp + (int64_t)zr * p.dt_sl) + bias;
+            dtv = softplus_f(raw);
+            sg = (raw > 20.0f) ? 1.0f : sigmoid_f(raw);                            // d softplus / d raw (identity above 20)
+        }
+        DT[tid] = dtv;
+        SIG[tid] = sg;
+        tab[T_TMP0 * SB_TAB + tid] = dtv;
+        zi[tid] = zr;
+        oi[tid] = orow;
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int off = 1; off < SB_TAB; off <<= 1) {                                  // inclusive prefix sum of dt (Hillis-Steele)
+        if (tid < SB_TAB) {
+            const float* src = tab + (T_TMP0 + cur) * SB_TAB;
+            tab[(T_TMP0 + (cur ^ 1)) * SB_TAB + tid] = src[tid] + (tid >= off ? src[tid - off] : 0.0f);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid < SB_TAB) {
+        const float c = tab[(T_TMP0 + cur) * SB_TAB + tid];
+        CUM[tid] = c;
+        S2[tid] = a2 * c;                                                         // log2-domain log-decay
+    }
+    __syncthreads();
+    if (tid < SB_TAB) {
+        const int t = tid >> 5;
+        const float sv = S2[tid];
+        const float m_t = t ? S2[SB_TILE * t - 1] : 0.0f, m_n = S2[SB_TILE * t + SB_TILE - 1];
+        const float al = fast_exp2(sv - m_t), ga = fast_exp2(m_n - sv);
+        ALPHA[tid] = al;
+        GAM[tid] = ga;
+        GDT[tid] = ga * DT[tid];
+    }
+    auto m_of = [&](int t) -> float { return t ? S2[SB_TILE * t - 1] : 0.0f; };   // log-decay just before tile t
+
+    // ---- phase 1: X, gY = dout .* silu(z) (both ways), B, C (both ways) into LDS; wave w moves 16-byte chunk w of every row ----
+    float dD_acc = 0.0f;
+    {
+        const int cb = hb + w * 16;
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int r = lane + 64 * j;
+            if (r < LR) {
+                ssd_u32x4 xv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
+                if (r < L) {
+                    const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, r * sl_x + cb, 0, 0);
+                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[r] * sl_do + cb, 0, 0);
+                    ssd_u32x4 zq = {0u, 0u, 0u, 0u};
+                    if (p.z) {
+                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[r] * sl_z + cb, 0, 0);
+                        zq = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+                    }
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float g0 = O::lo(dq[d]), g1 = O::hi(dq[d]);
+                        if (p.z) {
+                            g0 *= silu_f(O::lo(zq[d]));
+                            g1 *= silu_f(O::hi(zq[d]));
+                        }
+                        dD_acc += g0 * O::lo(xq[d]) + g1 * O::hi(xq[d]);
+                        xv[d] = xq[d];
+                        gv[d] = O::pack(g0, g1);
+                    }
+                }
+                const int so = r * 128 + ((w ^ (r & 7)) << 4);
+                *reinterpret_cast<ssd_u32x4*>(lds + SB_XS + so) = xv;
+                *reinterpret_cast<ssd_u32x4*>(lds + SB_GS + so) = gv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int to = (8 * w + e) * SB_TPITCH + r * 2;
+                    *reinterpret_cast<uint16_t*>(lds + SB_XT + to) = (uint16_t)((e & 1) ? (xv[e >> 1] >> 16) : (xv[e >> 1] & 0xffffu));
+                    *reinterpret_cast<uint16_t*>(lds + SB_GT + to) = (uint16_t)((e & 1) ? (gv[e >> 1] >> 16) : (gv[e >> 1] & 0xffffu));
+                }
+            }
+        }
+        const int r = tid >> 1, hf = tid & 1;                                     // B / C: two 16-byte chunks per row
+        if (r < LR) {
+            ssd_u32x4 bv = {0u, 0u, 0u, 0u}, cv = {0u, 0u, 0u, 0u};
+            if (r < L) {
+                const auto b = __builtin_amdgcn_raw_buffer_load_b128(r_B, r * sl_B + hf * 16, 0, 0);
+                const auto c = __builtin_amdgcn_raw_buffer_load_b128(r_C, r * sl_C + hf * 16, 0, 0);
+                bv = (ssd_u32x4){b[0], b[1], b[2], b[3]};
+                cv = (ssd_u32x4){c[0], c[1], c[2], c[3]};
+            }
+            *reinterpret_cast<ssd_u32x4*>(lds + SB_BS + r * 32 + hf * 16) = bv;
+            *reinterpret_cast<ssd_u32x4*>(lds + SB_CS + r * 32 + hf * 16) = cv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int to = (8 * hf + e) * SB_TPITCH + r * 2;
+                *reinterpret_cast<uint16_t*>(lds + SB_BT + to) = (uint16_t)((e & 1) ? (bv[e >> 1] >> 16) : (bv[e >> 1] & 0xffffu));
+                *reinterpret_cast<uint16_t*>(lds + SB_CT + to) = (uint16_t)((e & 1) ? (cv[e >> 1] >> 16) : (cv[e >> 1] & 0xffffu));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: the two orientations of the 28 tile pairs ---------------------------------------------------------------------
+    const int q = lane & 31, kh = lane >> 5;                                      // fragment role: row/column of a tile, K half
+    const int row8 = lane >> 3, c8 = lane & 7;                                    // epilogue role: row of an 8-row slab, 16-byte chunk
+    float* const stage = reinterpret_cast<float*>(lds + SB_STAGE) + w * 8 * SB_STG;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    if (w < 4) {
+        // ===== T orientation: query tile lt; rows of the score tile = keys (registers), columns = queries (lanes) =====
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int lt = pass == 0 ? 6 - w : w - 1;
+            if (lt < 0 || lt >= nt_l) continue;
+            const int ql = SB_TILE * lt + q;
+            const ssd_u32x4 cB = bc_frag(lds + SB_CS, ql, kh);
+            ssd_u32x4 gB[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) gB[ks] = row_frag(lds + SB_GS, ql, 2 * ks + kh);
+            const float s2q = S2[ql], aq = ALPHA[ql], mlt = m_of(lt);
+            f32x16 Y0 = zero16, Y1 = zero16, dC = zero16;
+            float rs = 0.0f;
+#pragma unroll 1
+            for (int it = 0; it <= lt; ++it) {
+                const int ki = SB_TILE * it + q;
+                f32x16 g = O::mfma(bc_frag(lds + SB_BS, ki, kh), cB, zero16);             // G[query][key]: keys 32it + 4kh + 8r4 + r in registers
+                f32x16 rr = zero16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(row_frag(lds + SB_XS, ki, 2 * ks + kh), gB[ks], rr);     // R = gY . X
+                const int kb = SB_TILE * it + 4 * kh;
+                float md[16];                                                     // M[query][key] * dt_key
+                if (it < lt) {
+                    const float cq = aq * fast_exp2(mlt - S2[SB_TILE * it + SB_TILE - 1]);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 f = *reinterpret_cast<const f32x4*>(&GDT[kb + 8 * r4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) md[4 * r4 + r] = cq * f[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 sk = *reinterpret_cast<const f32x4*>(&S2[kb + 8 * r4]);
+                        const f32x4 dk = *reinterpret_cast<const f32x4*>(&DT[kb + 8 * r4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) md[4 * r4 + r] = (kb + 8 * r4 + r <= ql) ? fast_exp2(s2q - sk[r]) * dk[r] : 0.0f;
+                    }
+                }
+                uint32_t wp[8], dp[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const float w0 = g[2 * r2] * md[2 * r2], w1 = g[2 * r2 + 1] * md[2 * r2 + 1];
+                    rs += w0 * rr[2 * r2] + w1 * rr[2 * r2 + 1];                   // row sum of R .* W
+                    wp[r2] = O::pack(w0, w1);
+                    dp[r2] = O::pack(rr[2 * r2] * md[2 * r2], rr[2 * r2 + 1] * md[2 * r2 + 1]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
+                    const ssd_u32x4 df = {dp[4 * ks], dp[4 * ks + 1], dp[4 * ks + 2], dp[4 * ks + 3]};
+                    const int k0 = kb + 16 * ks;
+                    Y0 = O::mfma(wf, t_frag(lds + SB_XT, q, k0), Y0);
+                    Y1 = O::mfma(wf, t_frag(lds + SB_XT, 32 + q, k0), Y1);
+                    dC = O::mfma(df, t_frag(lds + SB_BT, q & 15, k0, q < 16), dC);
+                }
+            }
+            rs += __shfl_xor(rs, 32);
+            if (kh == 0) RS[ql] = rs;
+            if (q < 16) {                                                         // dC[32lt + 4kh + 8r4 + r][state q], partial of this head
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = SB_TILE * lt + 4 * kh + 8 * r4 + r;
+                        if (row < L) dbc_part[row * 32 + 16 + q] = dC[4 * r4 + r];
+                    }
+            }
+            // dz = dout .* (Y + D x) .* silu'(z): 8 rows at a time through the staging tile
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stage[(4 * kh + r) * SB_STG + q] = Y0[4 * r4 + r];
+                    stage[(4 * kh + r) * SB_STG + 32 + q] = Y1[4 * r4 + r];
+                }
+                wave_lds_sync();
+                const f32x4 ua = *reinterpret_cast<const f32x4*>(&stage[row8 * SB_STG + 8 * c8]);
+                const f32x4 ub = *reinterpret_cast<const f32x4*>(&stage[row8 * SB_STG + 8 * c8 + 4]);
+                wave_lds_sync();
+                const int l = SB_TILE * lt + 8 * r4 + row8;
+                if (p.dz && l < L) {
+                    const ssd_u32x4 xq = row_frag(lds + SB_XS, l, c8);
+                    const int zr = zi[l];
+                    const auto zq = __builtin_amdgcn_raw_buffer_load_b128(r_z, zr * sl_z + hb + c8 * 16, 0, 0);
+                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[l] * sl_do + hb + c8 * 16, 0, 0);
+                    ssd_u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        float res[2];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const float u = (d < 2 ? ua[2 * d + e] : ub[2 * (d - 2) + e]) + Dh * (e ? O::hi(xq[d]) : O::lo(xq[d]));
+                            const float zv = e ? O::hi(zq[d]) : O::lo(zq[d]);
+                            const float dv = e ? O::hi(dq[d]) : O::lo(dq[d]);
+                            const float sg = sigmoid_f(zv);
+                            res[e] = dv * u * sg * (1.0f + zv * (1.0f - sg));
+                        }
+                        o[d] = O::pack(res[0], res[1]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, r_dz, zr * sl_dz + hb + c8 * 16, 0, 0);
+                }
+            }
+        }
+    } else {
+        // ===== N orientation: key tile it; rows of the score tile = queries (registers), columns = keys (lanes) =====
+        const int v = w - 4;
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+            const int it = pass == 0 ? v : 7 - v;
+            if ((pass == 1 && v == 0) || it >= nt_l) continue;
+            const int ki = SB_TILE * it + q;
+            const ssd_u32x4 bB = bc_frag(lds + SB_BS, ki, kh);
+            ssd_u32x4 xB[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xB[ks] = row_frag(lds + SB_XS, ki, 2 * ks + kh);
+            const float dtk = DT[ki], gamk = GAM[ki], s2k = S2[ki], mnext = S2[SB_TILE * it + SB_TILE - 1];
+            f32x16 X0 = zero16, X1 = zero16, dB = zero16;
+            float cv = 0.0f;
+#pragma unroll 1
+            for (int lt = it; lt < nt_l; ++lt) {
+                const int qrow = SB_TILE * lt + q;
+                f32x16 g = O::mfma(bc_frag(lds + SB_CS, qrow, kh), bB, zero16);           // G[query][key]: queries 32lt + 4kh + 8r4 + r in registers
+                f32x16 rr = zero16;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(row_frag(lds + SB_GS, qrow, 2 * ks + kh), xB[ks], rr);
+                const int qb = SB_TILE * lt + 4 * kh;
+                float mf[16];                                                     // M[query][key] (without dt)
+                if (lt > it) {
+                    const float ck = gamk * fast_exp2(m_of(lt) - mnext);
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(&ALPHA[qb + 8 * r4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mf[4 * r4 + r] = ck * a[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 sq = *reinterpret_cast<const f32x4*>(&S2[qb + 8 * r4]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mf[4 * r4 + r] = (ki <= qb + 8 * r4 + r) ? fast_exp2(sq[r] - s2k) : 0.0f;
+                    }
+                }
+                uint32_t wp[8], dp[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const float gm0 = g[2 * r2] * mf[2 * r2], gm1 = g[2 * r2 + 1] * mf[2 * r2 + 1];
+                    cv += gm0 * rr[2 * r2] + gm1 * rr[2 * r2 + 1];                 // column sum of V = R .* G .* M
+                    wp[r2] = O::pack(gm0 * dtk, gm1 * dtk);
+                    dp[r2] = O::pack(rr[2 * r2] * (mf[2 * r2] * dtk), rr[2 * r2 + 1] * (mf[2 * r2 + 1] * dtk));
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
+                    const ssd_u32x4 df = {dp[4 * ks], dp[4 * ks + 1], dp[4 * ks + 2], dp[4 * ks + 3]};
+                    const int q0 = qb + 16 * ks;
+                    X0 = O::mfma(wf, t_frag(lds + SB_GT, q, q0), X0);
+                    X1 = O::mfma(wf, t_frag(lds + SB_GT, 32 + q, q0), X1);
+                    dB = O::mfma(df, t_frag(lds + SB_CT, q & 15, q0, q < 16), dB);
+                }
+            }
+            cv += __shfl_xor(cv, 32);
+            if (kh == 0) CSV[ki] = cv;
+            if (q < 16) {
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = SB_TILE * it + 4 * kh + 8 * r4 + r;
+                        if (row < L) dbc_part[row * 32 + q] = dB[4 * r4 + r];
+                    }
+            }
+            // dx = W^T gY + D gY
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    stage[(4 * kh + r) * SB_STG + q] = X0[4 * r4 + r];
+                    stage[(4 * kh + r) * SB_STG + 32 + q] = X1[4 * r4 + r];
+                }
+                wave_lds_sync();
+                const f32x4 ua = *reinterpret_cast<const f32x4*>(&stage[row8 * SB_STG + 8 * c8]);
+                const f32x4 ub = *reinterpret_cast<const f32x4*>(&stage[row8 * SB_STG + 8 * c8 + 4]);
+                wave_lds_sync();
+                const int l = SB_TILE * it + 8 * r4 + row8;
+                if (l < L) {
+                    const ssd_u32x4 gq = row_frag(lds + SB_GS, l, c8);
+                    ssd_u32x4 o;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float u0 = (d < 2 ? ua[2 * d] : ub[2 * (d - 2)]) + Dh * O::lo(gq[d]);
+                        const float u1 = (d < 2 ? ua[2 * d + 1] : ub[2 * (d - 2) + 1]) + Dh * O::hi(gq[d]);
+                        o[d] = O::pack(u0, u1);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(o, r_dx, l * sl_dx + hb + c8 * 16, 0, 0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: d dt, dA, dD ------------------------------------------------------------------------------------------------
+    float csv = 0.0f, dsv = 0.0f;
+    if (tid < L) {
+        csv = CSV[tid];
+        dsv = RS[tid] - DT[tid] * csv;                                            // d s_l
+    }
+    {
+        const float a = wave_sum_dpp(dsv * ((tid < L) ? CUM[tid] : 0.0f)), d = wave_sum_dpp(dD_acc);
+        if (lane == 0) {
+            red[w] = a;
+            red[8 + w] = d;
+        }
+    }
+    if (tid < SB_TAB) tab[T_TMP0 * SB_TAB + tid] = dsv;
+    __syncthreads();
+    cur = 0;
+    for (int off = 1; off < SB_TAB; off <<= 1) {                                  // reverse inclusive cumulative sum of ds
+        if (tid < SB_TAB) {
+            const float* src = tab + (T_TMP0 + cur) * SB_TAB;
+            tab[(T_TMP0 + (cur ^ 1)) * SB_TAB + tid] = src[tid] + (tid + off < SB_TAB ? src[tid + off] : 0.0f);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    if (tid < L) {
+        const float ddt = csv + Ah * tab[(T_TMP0 + cur) * SB_TAB + tid];
+        p.ddt[((int64_t)s * L + zi[tid]) * H + h] = ddt * SIG[tid];
+    }
+    if (tid == 0) {
+        float a = 0.0f, d = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += red[k];
+            d += red[8 + k];
+        }
+        p.dA_part[(int64_t)s * H + h] = a;
+        p.dD_part[(int64_t)s * H + h] = d;
+    }
+}
+
+}  // namespace dm
+
+extern "C" int dm_ssd_bwd_supported(int seqlen, int headdim, int dstate, int io_dtype) {
+    return (seqlen >= 1 && seqlen <= dm::SB_MAXL && headdim == 64 && dstate == 16 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;
+}
+
+extern "C" int dm_ssd_bwd(const dm_ssd_bwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_ssd_bwd: null args"); return DM_ERR_ARG; }
+    const dm_ssd_bwd_args& a = *args;
+    if (!a.x || !a.B || !a.C || !a.dt || !a.dout || !a.A || !a.dx || !a.dBC_part || !a.ddt || !a.dA_part || !a.dD_part) {
+        set_error("dm_ssd_bwd: null tensor pointer"); return DM_ERR_ARG;
+    }
+    if ((a.z == nullptr) != (a.dz == nullptr)) { set_error("dm_ssd_bwd: z and dz go together"); return DM_ERR_ARG; }
+    if (a.nseq <= 0 || a.nheads <= 0 || a.seqlen <= 0) { set_error("dm_ssd_bwd: non-positive size"); return DM_ERR_ARG; }
+    if (!dm_ssd_bwd_supported(a.seqlen, a.headdim, a.dstate, a.io_dtype)) {
+        set_error("dm_ssd_bwd: needs 16-bit I/O, headdim 64, d_state 16, seqlen <= %d (got L %d P %d N %d dtype %d)", SB_MAXL, a.seqlen, a.headdim, a.dstate, a.io_dtype);
+        return DM_ERR_ARG;
+    }
+    if (a.nseq > 65535) { set_error("dm_ssd_bwd: nseq %d > 65535", a.nseq); return DM_ERR_ARG; }
+    if (a.batch_per_dir > 0 && a.nseq % a.batch_per_dir != 0) { set_error("dm_ssd_bwd: nseq %% batch_per_dir != 0"); return DM_ERR_ARG; }
+    if ((a.z_row_index == nullptr) != (a.out_row_index == nullptr)) { set_error("dm_ssd_bwd: both row-index tables or neither"); return DM_ERR_ARG; }
+    auto bad = [](const void* ptr, int64_t s0, int64_t s1) { return ((uintptr_t)ptr & 15) || (s0 & 7) || (s1 & 7); };
+    if (bad(a.x, a.x_ss, a.x_sl) || bad(a.B, a.B_ss, a.B_sl) || bad(a.C, a.C_ss, a.C_sl) || bad(a.dout, a.do_ss, a.do_sl) ||
+        bad(a.dx, a.dx_ss, a.dx_sl) || (a.z && (bad(a.z, a.z_ss, a.z_sl) || bad(a.dz, a.dz_ss, a.dz_sl)))) {
+        set_error("dm_ssd_bwd: rows must be 16-byte aligned (tiles move as 16-byte pieces)"); return DM_ERR_LAYOUT;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(a.nheads, a.nseq), block(SB_THREADS);
+    hipError_t e;
+    if (a.io_dtype == DM_BF16) {
+        static const hipError_t once = hipFuncSetAttribute((const void*)ssd_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES);
+        if (once != hipSuccess) { set_error("dm_ssd_bwd: cannot reserve %d bytes of LDS: %s", SB_LDS_BYTES, hipGetErrorString(once)); return DM_ERR_LAUNCH; }
+        hipLaunchKernelGGL((ssd_bwd_kernel<bf16_t>), grid, block, SB_LDS_BYTES, st, a);
+    } else {
+        static const hipError_t once = hipFuncSetAttribute((const void*)ssd_bwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES);
+        if (once != hipSuccess) { set_error("dm_ssd_bwd: cannot reserve %d bytes of LDS: %s", SB_LDS_BYTES, hipGetErrorString(once)); return DM_ERR_LAUNCH; }
+        hipLaunchKernelGGL((ssd_bwd_kernel<f16_t>), grid, block, SB_LDS_BYTES, st, a);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_ssd_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -699,3 +699,56 @@ def ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, *, z_row_index=None, out_
     es = x.element_size()
     _launch("dm_ssd_fwd", a, x, (3 if z is not None else 2) * S * L * Din * es + 2 * S * L * 16 * es)
     return out
+
+
+# Backward twin (csrc/ssd_bwd.hip): one workgroup per (sequence, head) recomputes the score tiles, nothing is saved by the
+# forward (no delta tensor, no checkpoints).  DIFFMA_SSD_MFMA_BWD=0 keeps Mamba-2 training on the A-shared scan pair.
+SSD_MFMA_BWD = os.environ.get("DIFFMA_SSD_MFMA_BWD", "1") == "1"
+
+
+def ssd_bwd_supported(x, L, headdim, dstate, views=()):
+    if not (SSD_MFMA and SSD_MFMA_BWD and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+        return False
+    for v in views:
+        if v is not None and (v.data_ptr() % 16 or v.stride(-1) != 1 or any(st % 8 for st in v.stride()[:-1])):
+            return False
+    return bool(_lib.load().dm_ssd_bwd_supported(int(L), int(headdim), int(dstate), dtype_code(x)))
+
+
+def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None, out_row_index=None, batch_per_dir=0, dx_out=None):
+    """Operands as ssd_fwd; dout: [S, L, H*64] gradient of the gated output, step l read at row out_row_index[dir][l].
+    Returns (dx [S, L, H*64] scan order (dx_out view if given), dz [S, L, H*64] token order per direction,
+    dBC_part fp32 [S, H, L, 32] (dB | dC per head), ddt fp32 [S, L, H] raw-dt gradient in token order per direction,
+    dA_part, dD_part fp32 [S, H])."""
+    _require_gpu(x, Bm, Cm, dt_tok, z, dout)
+    S, L, Din = x.shape
+    H = A_h.shape[0]
+    assert Din == H * 64 and Bm.shape[-1] == 16 and x.stride(2) == 1 and Bm.stride(2) == 1 and Cm.stride(2) == 1 and dt_tok.stride(2) == 1
+    assert dout.shape == (S, L, Din) and dout.stride(2) == 1 and dout.dtype == x.dtype
+    dx = dx_out if dx_out is not None else torch.empty((S, L, Din), dtype=x.dtype, device=x.device)
+    dz = torch.empty((S, L, Din), dtype=x.dtype, device=x.device) if z is not None else None
+    dbc = torch.empty((S, H, L, 32), dtype=torch.float32, device=x.device)
+    ddt = torch.empty((S, L, H), dtype=torch.float32, device=x.device)
+    dA = torch.empty((S, H), dtype=torch.float32, device=x.device)
+    dD = torch.empty((S, H), dtype=torch.float32, device=x.device)
+    A32, D32, b32 = _f32c(A_h), _f32c(D_h), _f32c(dt_bias_h)
+    a = dm_ssd_bwd_args()
+    a.nseq, a.batch_per_dir, a.seqlen, a.nheads, a.headdim, a.dstate = S, batch_per_dir, L, H, 64, 16
+    a.io_dtype, a.flags = dtype_code(x), 0
+    a.x, a.B, a.C, a.dt, a.z, a.dout = _ptr(x), _ptr(Bm), _ptr(Cm), _ptr(dt_tok), _ptr(z), _ptr(dout)
+    a.A, a.D, a.dt_bias = _ptr(A32), _ptr(D32), _ptr(b32)
+    a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
+    a.dx, a.dz = _ptr(dx), _ptr(dz)
+    a.dBC_part, a.ddt, a.dA_part, a.dD_part = _ptr(dbc), _ptr(ddt), _ptr(dA), _ptr(dD)
+    a.x_ss, a.x_sl = x.stride(0), x.stride(1)
+    a.B_ss, a.B_sl = Bm.stride(0), Bm.stride(1)
+    a.C_ss, a.C_sl = Cm.stride(0), Cm.stride(1)
+    a.dt_sb, a.dt_sl = dt_tok.stride(0), dt_tok.stride(1)
+    if z is not None:
+        a.z_ss, a.z_sl = z.stride(0), z.stride(1)
+        a.dz_ss, a.dz_sl = dz.stride(0), dz.stride(1)
+    a.do_ss, a.do_sl = dout.stride(0), dout.stride(1)
+    a.dx_ss, a.dx_sl = dx.stride(0), dx.stride(1)
+    es = x.element_size()
+    _launch("dm_ssd_bwd", a, x, (6 if z is not None else 3) * S * L * Din * es + 2 * S * L * 16 * es + S * H * L * 32 * 4)
+    return dx, dz, dbc, ddt, dA, dD

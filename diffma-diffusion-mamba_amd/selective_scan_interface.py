@@ -385,12 +385,18 @@ class _SpiralSSDFn(torch.autograd.Function):
         xBC = hip_ops.gather_conv1d_fwd(xbc_in, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)        # [S, L, Cx]
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         need_grad = grad_on and any(ctx.needs_input_grad[:7])
-        if not need_grad and hip_ops.ssd_fwd_supported(xBC, L, P, N, views=(x, Bm, Cm, z)):
-            # no-grad path on the matrix pipe (csrc/ssd.hip): single-chunk SSD as two dense products per (sequence, head), the
-            # per-head dt read in the kernel through the gather table -- no [S, L, Din] delta tensor, no per-state recurrence
+        ctx.ssd = False
+        if hip_ops.ssd_fwd_supported(xBC, L, P, N, views=(x, Bm, Cm, z)) and (not need_grad or hip_ops.ssd_bwd_supported(xBC, L, P, N)):
+            # the matrix pipe (csrc/ssd.hip, ssd_bwd.hip): single-chunk SSD as dense tile products per (sequence, head), the per-head
+            # dt read in the kernel through the gather table -- no [S, L, Din] delta tensor, no per-state recurrence, and nothing
+            # but the operands saved for the backward (which recomputes the score tiles)
             ydir = hip_ops.ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, z_row_index=scan_index, out_row_index=scan_index,
                                    batch_per_dir=Bsz)
-            out, _ = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+            out, rstd = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+            if need_grad:
+                ctx.ssd = True
+                ctx.save_for_backward(zxbcdt, conv_w, conv_b, xBC, A_h, D_h, dt_bias_h, ydir, rstd, norm_w, scan_index)
+                ctx.meta = (Din, N, H, P, eps, dt_bias_h.dtype, A_h.dtype, D_h.dtype)
             return out
         # dt is produced per token and per head: gather its rows per direction, broadcast head -> channels
         idx64 = scan_index.long()
@@ -409,6 +415,8 @@ class _SpiralSSDFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.ssd:
+            return _SpiralSSDFn._backward_matrix_pipe(ctx, dout)
         zxbcdt, conv_w, conv_b, xBC, delta, A, Dskip, dt_bias, ckpt, ydir, rstd, norm_w, scan_index, scan_index_inv = ctx.saved_tensors
         Din, N, H, P, eps, bias_dt, A_dt, D_dt = ctx.meta
         Bsz, L, _ = zxbcdt.shape
@@ -442,6 +450,36 @@ class _SpiralSSDFn(torch.autograd.Function):
         dbias_h = dbias.view(H, P).sum(-1)
         return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
                 dbias_h.to(bias_dt), dA_h.to(A_dt), dD_h.to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
+
+
+    @staticmethod
+    def _backward_matrix_pipe(ctx, dout):
+        zxbcdt, conv_w, conv_b, xBC, A_h, D_h, dt_bias_h, ydir, rstd, norm_w, scan_index = ctx.saved_tensors
+        Din, N, H, P, eps, bias_dt, A_dt, D_dt = ctx.meta
+        Bsz, L, _ = zxbcdt.shape
+        ndir = scan_index.shape[0]
+        S, Cx = ndir * Bsz, Din + 2 * N
+        dt_ = zxbcdt.dtype
+        if dout.dtype != dt_:
+            dout = dout.to(dt_)
+        dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
+        dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
+        x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
+        _, dzs, dbc_part, ddt, dA_part, dD_part = hip_ops.ssd_bwd(
+            x, Bm, Cm, zxbcdt[..., Din + Cx:], zxbcdt[..., :Din], dyd.view(S, L, Din), A_h, D_h, dt_bias_h, z_row_index=scan_index,
+            out_row_index=scan_index, batch_per_dir=Bsz, dx_out=dxBC[..., :Din])
+        dxBC[..., Din:].copy_(dbc_part.sum(1))                                        # heads share B and C: dB | dC in their xBC columns
+        dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(zxbcdt[..., Din:Din + Cx], conv_w, conv_b, dxBC, row_index=scan_index,
+                                                               ndir=ndir, silu=True)                              # token order
+        dzx = torch.empty_like(zxbcdt)
+        hip_ops.token_merge(dzs.view(ndir, Bsz, L, Din), out=dzx[..., :Din])
+        hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Cx), out=dzx[..., Din:Din + Cx])
+        ddt4 = ddt.view(ndir, Bsz, L, H)                                              # already in token order, raw-dt gradient: add the directions
+        ddt_tok = ddt4[0] if ndir == 1 else ddt4.sum(0)
+        dzx[..., Din + Cx:].copy_(ddt_tok)
+        dbias_h = ddt_tok.sum((0, 1))
+        return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
+                dbias_h.to(bias_dt), dA_part.sum(0).to(A_dt), dD_part.sum(0).to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
 
 
 def spiral_ssd(zxbcdt, conv_w, conv_b, dt_bias, A, D, norm_w, eps, scan_index, scan_index_inv, d_inner, d_state):

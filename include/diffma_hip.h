@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 15
+#define DM_ABI_VERSION 16
 
 typedef enum {
     DM_OK = 0,
@@ -406,6 +406,39 @@ typedef struct {
 
 int dm_ssd_fwd(const dm_ssd_fwd_args *args, void *stream);
 int dm_ssd_fwd_supported(int seqlen, int headdim, int dstate, int io_dtype);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward twin of dm_ssd_fwd (same operator, same operands; SURVEY.md A.2, reference call block/mamba2.py:392-410 under
+ * autograd).  Nothing is saved by the forward: one workgroup per (sequence, head) recomputes the score tiles.
+ *   dout: [nseq][rows][nheads*64] gradient of the GATED output, step l read at row out_row_index[dir][l] (token order per
+ *         sequence, as dm_rmsnorm_merge_bwd leaves it);
+ *   dx:   [nseq][L][..] view (scan order; the x columns of the conv output's gradient);
+ *   dz:   [nseq][rows][nheads*64], step l written at row z_row_index[dir][l] (token order per direction: dm_token_merge sums them);
+ *   dBC_part: fp32 [nseq][nheads][L][32]  per-head partial rows  dB (0..15) | dC (16..31) -- the caller sums over heads;
+ *   ddt:  fp32 [nseq][rows][nheads], gradient of the RAW per-head dt (through softplus), step l at row z_row_index[dir][l];
+ *   dA_part, dD_part: fp32 [nseq][nheads] partial sums (the caller sums over sequences; d dt_bias = sum of ddt).
+ * 16-bit I/O, headdim 64, d_state 16, seqlen <= 196, 16-byte aligned rows: dm_ssd_bwd_supported() tells.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t nseq, batch_per_dir, seqlen, nheads, headdim, dstate;
+    int32_t io_dtype, flags;
+    const void *x, *B, *C, *dt, *z, *dout;
+    const float *A, *D, *dt_bias;       /* [nheads] fp32 (D, dt_bias may be NULL) */
+    const int32_t *z_row_index, *out_row_index;
+    void *dx, *dz;
+    float *dBC_part, *ddt, *dA_part, *dD_part;
+    int64_t x_ss, x_sl;
+    int64_t B_ss, B_sl;
+    int64_t C_ss, C_sl;
+    int64_t dt_sb, dt_sl;
+    int64_t z_ss, z_sl;
+    int64_t do_ss, do_sl;
+    int64_t dx_ss, dx_sl;
+    int64_t dz_ss, dz_sl;
+} dm_ssd_bwd_args;
+
+int dm_ssd_bwd(const dm_ssd_bwd_args *args, void *stream);
+int dm_ssd_bwd_supported(int seqlen, int headdim, int dstate, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * One reverse-diffusion step after the denoiser call, fused (reference diffusion/gaussian_diffusion.py:285-323

@@ -666,3 +666,69 @@ def test_ssd_fwd_mfma_matches_oracle(gpu, dtype, Bsz, L, H, ndir, with_z):
                                 a_shared=True)
         sc = max(1.0, ref2.float().abs().max().item())
         torch.testing.assert_close(out.float(), ref2.float().cpu(), rtol=rtol, atol=atol * sc)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,H,ndir", [(2, 196, 2, 3), (1, 49, 3, 3), (2, 16, 1, 1), (1, 33, 2, 2), (1, 1, 1, 1), (1, 64, 1, 2), (1, 130, 2, 1)])
+def test_ssd_bwd_mfma_matches_oracle_autograd(gpu, dtype, Bsz, L, H, ndir):
+    """K6b (csrc/ssd_bwd.hip): every gradient of the Mamba-2 single-chunk SSD core against fp64 autograd through the sequential
+    restatement (oracle/mamba2_ref.ssd_scan_ref, pinned by G10) on the ROUNDED inputs: dx (scan order), dz and d(raw dt) (token
+    order per direction, through the row tables), dB / dC (per-head partials summed), dA, dD, d(dt_bias); ragged L, 1..3 directions."""
+    from diffma_amd import hip_ops
+    from oracle.mamba2_ref import ssd_scan_ref
+    from oracle.mamba_ref import softplus_ref
+
+    P, N = 64, 16
+    Din, S = H * P, Bsz * ndir
+    g = torch.Generator().manual_seed(L * 13 + H * 3 + ndir)
+    xBC = torch.randn(S, L, Din + 2 * N, generator=g).to(dtype)
+    dt_tok = (torch.randn(Bsz, L, H, generator=g) * 0.7 - 1.0).to(dtype)
+    ztok = torch.randn(Bsz, L, Din, generator=g).to(dtype)
+    dout = torch.randn(S, L, Din, generator=g).to(dtype)
+    A_h = -(torch.rand(H, generator=g) * 6 + 0.3)
+    D_h, bias_h = torch.randn(H, generator=g), torch.randn(H, generator=g) * 0.5
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    dev = lambda t: t.to(gpu)
+    xb = dev(xBC)
+    dxBC = torch.full((S, L, Din + 2 * N), float("nan"), dtype=dtype, device=gpu)       # dx lands in a strided view, as in the mixer
+    dx, dz, dbc, ddt, dA, dD = hip_ops.ssd_bwd(xb[..., :Din], xb[..., Din:Din + N], xb[..., Din + N:], dev(dt_tok), dev(ztok), dev(dout), dev(A_h),
+                                               dev(D_h), dev(bias_h), z_row_index=dev(perms), out_row_index=dev(perms), batch_per_dir=Bsz,
+                                               dx_out=dxBC[..., :Din])
+    torch.cuda.synchronize()
+    assert dx.data_ptr() == dxBC.data_ptr() and torch.isnan(dxBC[..., Din:].float()).all()
+
+    d64 = lambda t: t.float().double()
+    A_r, D_r, b_r = (t.double().requires_grad_(True) for t in (A_h, D_h, bias_h))
+    leaves = []
+    loss = 0.0
+    for s_ in range(S):
+        k, b = divmod(s_, Bsz)
+        idx = perms[k].long()
+        xs = d64(xBC[s_, :, :Din]).requires_grad_(True)
+        Bs = d64(xBC[s_, :, Din:Din + N]).requires_grad_(True)
+        Cs = d64(xBC[s_, :, Din + N:]).requires_grad_(True)
+        raw = d64(dt_tok[b]).requires_grad_(True)                                           # token order, one leaf per sequence
+        zz = d64(ztok[b]).requires_grad_(True)
+        dt = softplus_ref(raw[idx] + b_r)[None]
+        y = ssd_scan_ref(xs[None], dt, A_r, Bs[None], Cs[None], D_r, P)[0]
+        zg = zz[idx]
+        out = y * (zg * torch.sigmoid(zg))
+        loss = loss + (out * d64(dout[s_])[idx]).sum()                                       # step l's gradient sits at row idx[l]
+        leaves.append((xs, Bs, Cs, raw, zz))
+    loss.backward()
+
+    rtol, atol = TOL[dtype]
+
+    def close(got, ref, what, slack=1.0):
+        got = got.float().cpu().double()
+        torch.testing.assert_close(got, ref, rtol=rtol * slack, atol=atol * slack * max(1.0, ref.abs().max().item()), msg=lambda m: f"{what}: {m}")
+
+    close(dx, torch.stack([lv[0].grad for lv in leaves]), "dx")
+    close(dz, torch.stack([lv[4].grad for lv in leaves]), "dz")
+    close(ddt, torch.stack([lv[3].grad for lv in leaves]), "d raw dt")
+    dbc_sum = dbc.sum(1)
+    close(dbc_sum[..., :N], torch.stack([lv[1].grad for lv in leaves]), "dB")
+    close(dbc_sum[..., N:], torch.stack([lv[2].grad for lv in leaves]), "dC")
+    close(dA.sum(0), A_r.grad, "dA")
+    close(dD.sum(0), D_r.grad, "dD")
+    close(ddt.sum((0, 1)), b_r.grad, "d dt_bias")

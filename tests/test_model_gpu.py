@@ -679,9 +679,11 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
     assert calls["n"] > n0
 
 
-def test_mamba2_mixer_inference_on_the_mfma_ssd_prototype(gpu, monkeypatch):
+@pytest.mark.parametrize("d_model,expect_calls", [(256, 1), (64, 0)])
+def test_mamba2_mixer_inference_on_the_mfma_ssd_prototype(gpu, monkeypatch, d_model, expect_calls):
     """The matrix-pipe SSD forward (csrc/ssd.hip; DIFFMA_SSD_MFMA, on by default) inside the Mamba-2 mixer under no_grad + bf16
-    autocast, against the fp64 oracle mixer."""
+    autocast, against the fp64 oracle mixer.  The kernel moves 16-byte row pieces: with nheads % 8 != 0 (d_model 64: 2 heads) the
+    z rows of the in_proj output are not 16-byte aligned and the mixer must take the A-shared scan instead -- same result."""
     from diffma_amd import hip_ops
     from diffma_amd.mamba2 import Mamba2
     from diffma_amd.tools import spiral
@@ -700,12 +702,64 @@ def test_mamba2_mixer_inference_on_the_mfma_ssd_prototype(gpu, monkeypatch):
     n = 14
     orders, inverses = spiral(n)
     lists = (orders[6], orders[7], inverses[6], inverses[7])
-    mix = Mamba2(d_model=64, d_state=16, d_conv=4, expand=2, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+    mix = Mamba2(d_model=d_model, d_state=16, d_conv=4, expand=2, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
                  origina_list_reversal=lists[3]).to(gpu).eval()
-    x = torch.randn(2, n * n, 64, device=gpu)
+    x = torch.randn(2, n * n, d_model, device=gpu)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
         y = mix(x, "spiral").float()
-    assert calls["n"] == 1
+    assert calls["n"] == expect_calls
     params = {k: v.detach().cpu().double() for k, v in mix.state_dict().items()}
     yr = mamba2_spiral_forward_ref(x.cpu().double(), params, lists, headdim=64, dtype=torch.float64)
     assert rel_l2(y.cpu(), yr) <= 2e-2, rel_l2(y.cpu(), yr)
+
+
+@pytest.mark.parametrize("n", [14, 7])
+def test_mamba2_mixer_training_on_the_matrix_pipe(gpu, monkeypatch, n):
+    """Mamba-2 mixer forward + backward under bf16 autocast with 8 heads (16-byte aligned rows): the autograd node must run
+    csrc/ssd.hip forward and csrc/ssd_bwd.hip backward (no scan launch at all), and every gradient must match fp64 autograd
+    through the oracle mixer within bf16 tolerance; the same step on the A-shared scan pair (DIFFMA_SSD_MFMA_BWD off) agrees too."""
+    from diffma_amd import hip_ops
+    from diffma_amd.mamba2 import Mamba2
+    from diffma_amd.tools import spiral
+    from oracle.mamba2_ref import mamba2_spiral_forward_ref
+
+    calls = {"ssd_fwd": 0, "ssd_bwd": 0, "scan_fwd": 0, "scan_bwd": 0}
+    for name in calls:
+        real = getattr(hip_ops, name)
+        monkeypatch.setattr(hip_ops, name, (lambda real, name: lambda *a, **k: (calls.__setitem__(name, calls[name] + 1), real(*a, **k))[1])(real, name))
+    torch.manual_seed(n)
+    orders, inverses = spiral(n)
+    lists = (orders[2], orders[3], inverses[2], inverses[3])
+    d_model = 256
+    mix = Mamba2(d_model=d_model, d_state=16, d_conv=4, expand=2, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+                 origina_list_reversal=lists[3]).to(gpu)
+    with torch.no_grad():
+        mix.norm.weight.add_(torch.randn_like(mix.norm.weight) * 0.1)
+        mix.D.add_(torch.randn_like(mix.D) * 0.1)
+    x = torch.randn(2, n * n, d_model, device=gpu, requires_grad=True)
+    dy = torch.randn(2, n * n, d_model, device=gpu)
+
+    def step():
+        x.grad = None
+        mix.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mix(x, "spiral")
+        (y.float() * dy).sum().backward()
+        return y.detach().float().cpu(), x.grad.detach().cpu().clone(), {k: p.grad.detach().float().cpu().clone() for k, p in mix.named_parameters()}
+
+    y, gx, gp = step()
+    assert calls == {"ssd_fwd": 1, "ssd_bwd": 1, "scan_fwd": 0, "scan_bwd": 0}, calls
+    params = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mix.state_dict().items()}
+    x64 = x.detach().cpu().double().requires_grad_(True)
+    yr = mamba2_spiral_forward_ref(x64, params, lists, headdim=64, dtype=torch.float64)
+    (yr * dy.cpu().double()).sum().backward()
+    assert rel_l2(y, yr.detach()) <= 2e-2, rel_l2(y, yr.detach())
+    assert rel_l2(gx, x64.grad) <= 3e-2, rel_l2(gx, x64.grad)
+    for k in gp:
+        assert rel_l2(gp[k], params[k].grad) <= 4e-2, (k, rel_l2(gp[k], params[k].grad))
+    monkeypatch.setattr(hip_ops, "SSD_MFMA_BWD", False)                     # training back on the scan pair
+    y2, gx2, gp2 = step()
+    assert calls["scan_fwd"] == 1 and calls["scan_bwd"] == 1 and calls["ssd_bwd"] == 1
+    assert rel_l2(y, y2) <= 2e-2 and rel_l2(gx, gx2) <= 3e-2
+    for k in gp:
+        assert rel_l2(gp[k], gp2[k]) <= 4e-2, (k, rel_l2(gp[k], gp2[k]))

@@ -45,9 +45,26 @@ for B in [int(a) for a in (sys.argv[1:] or ["8", "64", "256"])]:
         dtg = torch.stack([dt_tok[:, idx64[k]] for k in range(3)]).reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din)
         return hip_ops.scan_fwd(x, dtg, A, Bm, Cm, Dp, z, bp, True, z_row_index=idx, out_row_index=idx, batch_per_dir=B, a_shared=True, out=out)
 
+    # ---- backward: K6b against the A-shared scan backward (which also needs the forward's checkpoints and the expanded delta) ----
+    dout = torch.randn(S, L, Din, device=dev).to(dt_)
+    dxBC = torch.empty_like(xBC)
+
+    def mfma_bwd():
+        return hip_ops.ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, b_h, z_row_index=idx, out_row_index=idx, batch_per_dir=B, dx_out=dxBC[..., :Din])
+
+    dtg = torch.stack([dt_tok[:, idx64[k]] for k in range(3)]).reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, dt_, dev)
+    hip_ops.scan_fwd(x, dtg, A, Bm, Cm, Dp, z, bp, True, z_row_index=idx, out_row_index=idx, batch_per_dir=B, a_shared=True, out=out, ckpt=ckpt)
+
+    def scan_bwd():
+        return hip_ops.scan_bwd(x, dtg, A, Bm, Cm, Dp, z, bp, dout, ckpt, True, z_row_index=idx, out_row_index=idx, batch_per_dir=B, dout_per_seq=True,
+                                du_out=dxBC[..., :Din], a_shared=True, dbc_out=dxBC[..., Din:])
+
+    t_mb, t_sb = timeit(mfma_bwd), timeit(scan_bwd)
     a = mfma().float().clone()
     b = scan().float()
     nb = 3 * S * L * Din * 2
     t_m, t_s = timeit(mfma), timeit(scan)
     print(json.dumps(dict(batch=B, nseq=S, ssd_mfma_us=round(t_m, 1), a_shared_scan_us=round(t_s, 1), mfma_GBps=round(nb / t_m / 1e3, 1),
+                          ssd_bwd_mfma_us=round(t_mb, 1), a_shared_scan_bwd_us=round(t_sb, 1),
                           max_abs_diff=float((a - b).abs().max()), scale=float(b.abs().max()))))
