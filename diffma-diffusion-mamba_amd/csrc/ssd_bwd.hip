@@ -26,23 +26,27 @@ namespace dm {
 
 typedef uint32_t ssd_u32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int SB_MAXL = 196;                      // rows held in LDS
+constexpr int SB_MAXL = 196;                      // longest sequence
 constexpr int SB_TILE = 32, SB_MAXT = 7;
-constexpr int SB_TAB = SB_TILE * SB_MAXT;         // 224 table slots (tile-rounded)
+constexpr int SB_TAB = SB_TILE * SB_MAXT;         // 224 tile-rounded positions
 constexpr int SB_TPITCH = SB_MAXL * 2;            // bytes per row of a transposed array: 98 dwords = 2 mod 32 banks
 constexpr int SB_THREADS = 512;
 constexpr int SB_STG = 68;                        // dwords per staging-tile row (64 + 4)
 
 // LDS map (byte offsets)
-constexpr int SB_XS = 0;                          // X   [196][64]  16-byte chunks XOR-swizzled by (row & 7)
-constexpr int SB_GS = SB_XS + SB_MAXL * 128;      // gY  [196][64]  same layout
-constexpr int SB_XT = SB_GS + SB_MAXL * 128;      // X^T [64][196]
+// Row-major arrays hold all 224 tile-rounded rows, zero past the sequence, so fragment addresses are affine in the tile index
+// (no clamps, no selects).  The transposed arrays hold 196 positions per row: a fragment of the last tile that runs past position
+// 195 reads the head of the NEXT row / array -- finite 16-bit data that only ever meets exact zeros in the other operand (the
+// score-tile entries of positions >= L are 0 because dt, B, C and gY are zero there); a zero pad follows the last array.
+constexpr int SB_XS = 0;                          // X   [224][64]  16-byte chunks XOR-swizzled by (row & 7)
+constexpr int SB_GS = SB_XS + SB_TAB * 128;       // gY  [224][64]  same layout
+constexpr int SB_XT = SB_GS + SB_TAB * 128;       // X^T [64][196]
 constexpr int SB_GT = SB_XT + 64 * SB_TPITCH;     // gY^T[64][196]
-constexpr int SB_BS = SB_GT + 64 * SB_TPITCH;     // B   [196][16]
-constexpr int SB_CS = SB_BS + SB_MAXL * 32;       // C   [196][16]
-constexpr int SB_BT = SB_CS + SB_MAXL * 32;       // B^T [16][196]
-constexpr int SB_CT = SB_BT + 16 * SB_TPITCH;     // C^T [16][196]
-constexpr int SB_TABS = SB_CT + 16 * SB_TPITCH;   // fp32 tables [T_NTAB][224]
+constexpr int SB_BS = SB_GT + 64 * SB_TPITCH;     // B   [224][16]
+constexpr int SB_CS = SB_BS + SB_TAB * 32;        // C   [224][16]
+constexpr int SB_BT = SB_CS + SB_TAB * 32;        // B^T [16][196]
+constexpr int SB_CT = SB_BT + 16 * SB_TPITCH;     // C^T [16][196] + 64 B of zeros
+constexpr int SB_TABS = SB_CT + 16 * SB_TPITCH + 64;   // fp32 tables [T_NTAB][224]
 enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_TMP0, T_TMP1, T_NTAB };
 constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // int tables: z rows, dout rows
 constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 4;         // 8 waves x [8][SB_STG] fp32
@@ -56,26 +60,20 @@ __device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 8 consecutive columns (chunk) of a row of the swizzled [196][64] arrays, as an MFMA operand fragment; rows past the end read 0
+// 8 consecutive columns (chunk) of a row of the swizzled [224][64] arrays, as an MFMA operand fragment
 __device__ __forceinline__ ssd_u32x4 row_frag(const uint8_t* base, int row, int chunk) {
-    const int rc = row < SB_MAXL ? row : SB_MAXL - 1;
-    const ssd_u32x4 v = *reinterpret_cast<const ssd_u32x4*>(base + rc * 128 + ((chunk ^ (rc & 7)) << 4));
-    return row < SB_MAXL ? v : (ssd_u32x4){0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const ssd_u32x4*>(base + row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 // 8 states of a B / C row
 __device__ __forceinline__ ssd_u32x4 bc_frag(const uint8_t* base, int row, int kh) {
-    const int rc = row < SB_MAXL ? row : SB_MAXL - 1;
-    const ssd_u32x4 v = *reinterpret_cast<const ssd_u32x4*>(base + rc * 32 + kh * 16);
-    return row < SB_MAXL ? v : (ssd_u32x4){0u, 0u, 0u, 0u};
+    return *reinterpret_cast<const ssd_u32x4*>(base + row * 32 + kh * 16);
 }
 // B-operand of a product whose K index runs over sequence positions in ACCUMULATOR order: slots 0-3 = positions k0..k0+3, slots
-// 4-7 = k0+8..k0+11 of row `prow` of a transposed array (k0 = 32 tile + 4 kh + 16 ks); positions past the end read 0
-__device__ __forceinline__ ssd_u32x4 t_frag(const uint8_t* base, int prow, int k0, bool live = true) {
-    const int a = k0 < SB_MAXL ? k0 : 0, b = k0 + 8 < SB_MAXL ? k0 + 8 : 0;
-    const ssd_u32x2 lo = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + a * 2);
-    const ssd_u32x2 hi = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + b * 2);
-    const bool la = live && k0 < SB_MAXL, lb = live && k0 + 8 < SB_MAXL;
-    return (ssd_u32x4){la ? lo.x : 0u, la ? lo.y : 0u, lb ? hi.x : 0u, lb ? hi.y : 0u};
+// 4-7 = k0+8..k0+11 of row `prow` of a transposed array (k0 = 32 tile + 4 kh + 16 ks)
+__device__ __forceinline__ ssd_u32x4 t_frag(const uint8_t* base, int prow, int k0) {
+    const ssd_u32x2 lo = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2);
+    const ssd_u32x2 hi = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2 + 16);
+    return (ssd_u32x4){lo.x, lo.y, hi.x, hi.y};
 }
 
 template <typename T>
@@ -105,7 +103,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
     const int nt_l = (L + SB_TILE - 1) / SB_TILE;
-    const int LR = (SB_TILE * nt_l < SB_MAXL) ? SB_TILE * nt_l : SB_MAXL;          // LDS rows to fill (zeros past L)
+    const int LR = SB_TILE * nt_l;                                                // LDS rows to fill (zeros past L)
     const int32_t* __restrict__ zidx = p.z_row_index ? p.z_row_index + (int64_t)dir * L : nullptr;
     const int32_t* __restrict__ oidx = p.out_row_index ? p.out_row_index + (int64_t)dir * L : nullptr;
     const float Ah = p.A[h], a2 = Ah * LOG2E, Dh = p.D ? p.D[h] : 0.0f, bias = p.dt_bias ? p.dt_bias[h] : 0.0f;
@@ -170,19 +168,28 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     float dD_acc = 0.0f;
     {
         const int cb = hb + w * 16;
-#pragma unroll 1
+        ssd_u32x4 xq4[4], dq4[4], zq4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                                             // all 12 loads in flight before the first use
+            const int r = lane + 64 * j;
+            const int rc = r < L ? r : L - 1;
+            const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, rc * sl_x + cb, 0, 0);
+            const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[rc] * sl_do + cb, 0, 0);
+            xq4[j] = (ssd_u32x4){xq[0], xq[1], xq[2], xq[3]};
+            dq4[j] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
+            zq4[j] = (ssd_u32x4){0u, 0u, 0u, 0u};
+            if (p.z) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[rc] * sl_z + cb, 0, 0);
+                zq4[j] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+            }
+        }
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = lane + 64 * j;
             if (r < LR) {
                 ssd_u32x4 xv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
                 if (r < L) {
-                    const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, r * sl_x + cb, 0, 0);
-                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[r] * sl_do + cb, 0, 0);
-                    ssd_u32x4 zq = {0u, 0u, 0u, 0u};
-                    if (p.z) {
-                        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[r] * sl_z + cb, 0, 0);
-                        zq = (ssd_u32x4){v[0], v[1], v[2], v[3]};
-                    }
+                    const ssd_u32x4 xq = xq4[j], dq = dq4[j], zq = zq4[j];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         float g0 = O::lo(dq[d]), g1 = O::hi(dq[d]);
@@ -200,12 +207,14 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                 *reinterpret_cast<ssd_u32x4*>(lds + SB_GS + so) = gv;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
+                    if (r >= SB_MAXL) break;                                     // the transposed arrays end at position 195
                     const int to = (8 * w + e) * SB_TPITCH + r * 2;
                     *reinterpret_cast<uint16_t*>(lds + SB_XT + to) = (uint16_t)((e & 1) ? (xv[e >> 1] >> 16) : (xv[e >> 1] & 0xffffu));
                     *reinterpret_cast<uint16_t*>(lds + SB_GT + to) = (uint16_t)((e & 1) ? (gv[e >> 1] >> 16) : (gv[e >> 1] & 0xffffu));
                 }
             }
         }
+        if (tid < 16) *reinterpret_cast<uint32_t*>(lds + SB_CT + 16 * SB_TPITCH + 4 * tid) = 0u;      // the pad behind the last transposed array
         const int r = tid >> 1, hf = tid & 1;                                     // B / C: two 16-byte chunks per row
         if (r < LR) {
             ssd_u32x4 bv = {0u, 0u, 0u, 0u}, cv = {0u, 0u, 0u, 0u};
@@ -219,6 +228,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
             *reinterpret_cast<ssd_u32x4*>(lds + SB_CS + r * 32 + hf * 16) = cv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
+                if (r >= SB_MAXL) break;
                 const int to = (8 * hf + e) * SB_TPITCH + r * 2;
                 *reinterpret_cast<uint16_t*>(lds + SB_BT + to) = (uint16_t)((e & 1) ? (bv[e >> 1] >> 16) : (bv[e >> 1] & 0xffffu));
                 *reinterpret_cast<uint16_t*>(lds + SB_CT + to) = (uint16_t)((e & 1) ? (cv[e >> 1] >> 16) : (cv[e >> 1] & 0xffffu));
@@ -245,6 +255,20 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) gB[ks] = row_frag(lds + SB_GS, ql, 2 * ks + kh);
             const float s2q = S2[ql], aq = ALPHA[ql], mlt = m_of(lt);
+            ssd_u32x4 zq4[4], dq4[4];                                             // the epilogue's z / dout pieces, in flight under the products
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int l = SB_TILE * lt + 8 * r4 + row8;
+                const int lc = l < L ? l : L - 1;
+                zq4[r4] = (ssd_u32x4){0u, 0u, 0u, 0u};
+                dq4[r4] = (ssd_u32x4){0u, 0u, 0u, 0u};
+                if (p.dz) {
+                    const auto zq = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[lc] * sl_z + hb + c8 * 16, 0, 0);
+                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[lc] * sl_do + hb + c8 * 16, 0, 0);
+                    zq4[r4] = (ssd_u32x4){zq[0], zq[1], zq[2], zq[3]};
+                    dq4[r4] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
+                }
+            }
             f32x16 Y0 = zero16, Y1 = zero16, dC = zero16;
             float rs = 0.0f;
 #pragma unroll 1
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                     const int k0 = kb + 16 * ks;
                     Y0 = O::mfma(wf, t_frag(lds + SB_XT, q, k0), Y0);
                     Y1 = O::mfma(wf, t_frag(lds + SB_XT, 32 + q, k0), Y1);
-                    dC = O::mfma(df, t_frag(lds + SB_BT, q & 15, k0, q < 16), dC);
+                    dC = O::mfma(df, t_frag(lds + SB_BT, q & 15, k0), dC);                    // (columns 16-31 of the result are unused copies)
                 }
             }
             rs += __shfl_xor(rs, 32);
@@ -318,8 +342,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                 if (p.dz && l < L) {
                     const ssd_u32x4 xq = row_frag(lds + SB_XS, l, c8);
                     const int zr = zi[l];
-                    const auto zq = __builtin_amdgcn_raw_buffer_load_b128(r_z, zr * sl_z + hb + c8 * 16, 0, 0);
-                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[l] * sl_do + hb + c8 * 16, 0, 0);
+                    const ssd_u32x4 zq = zq4[r4], dq = dq4[r4];
                     ssd_u32x4 o;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -393,7 +416,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                     const int q0 = qb + 16 * ks;
                     X0 = O::mfma(wf, t_frag(lds + SB_GT, q, q0), X0);
                     X1 = O::mfma(wf, t_frag(lds + SB_GT, 32 + q, q0), X1);
-                    dB = O::mfma(df, t_frag(lds + SB_CT, q & 15, q0, q < 16), dB);
+                    dB = O::mfma(df, t_frag(lds + SB_CT, q & 15, q0), dB);
                 }
             }
             cv += __shfl_xor(cv, 32);
