@@ -1,4 +1,4 @@
-// K6  dm_ssd_fwd -- Mamba-2 state-space duality, single chunk, on the matrix pipe (forward, no-grad path).
+// K6  dm_ssd_fwd -- Mamba-2 state-space duality, single chunk, on the matrix pipe (forward).
 //
 // Replaces the SSD core of mamba_split_conv1d_scan_combined (reference call block/mamba2.py:392-410; mathematics SURVEY.md A.2)
 // after the conv: with chunk_size 256 >= L the operator is ONE chunk, and because Mamba-2's decay is a scalar per head the
@@ -14,7 +14,7 @@
 // loop has no memory operation at all except the broadcast reads of the log-decays from LDS.  z is gathered and the output
 // scattered through the row-index tables exactly like the scan kernels (CrossScan / CrossMerge folded into addressing); the
 // per-head dt is read in the kernel (token order, through the gather table), no [nseq, L, Din] delta tensor exists.
-// 16-bit I/O only (the score tile is rounded to the I/O dtype); fp32 I/O and the training path stay on the A-shared scan.
+// 16-bit I/O only (the score tile is rounded to the I/O dtype); fp32 I/O stays on the A-shared scan.  Backward twin: ssd_bwd.hip.
 #include <type_traits>
 #include "dm_common.h"
 #include "ssd_common.h"

@@ -652,13 +652,13 @@ def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0,
 
 
 # ------------------------------------------------------------------------------------------------
-# Mamba-2 SSD core on the matrix pipe (csrc/ssd.hip): the no-grad path of --use-mamba2
+# Mamba-2 SSD core on the matrix pipe (csrc/ssd.hip, csrc/ssd_bwd.hip): --use-mamba2 with 16-bit activations
 # ------------------------------------------------------------------------------------------------
-# On by default for 16-bit inference ("keep it only if it beats the A-shared scan" -- it does, DiffMa-XL/2
+# On by default ("keep it only if it beats the A-shared scan" -- it does, DiffMa-XL/2
 # mixer shape, 16 heads x 64, L 196: 26 vs 68 us at nseq 24, 101 vs 183 us at nseq 192, 415 vs 513 us at nseq 768, tools/bench_ssd.py).
 # One wave per (sequence, head, 32-column half); the decay is factorised per tile pair so only the diagonal tiles take
 # element-wise exps; X / z / out tiles move as 16-byte row pieces through LDS.  DIFFMA_SSD_MFMA=0 returns the no-grad Mamba-2
-# mixer to the A-shared scan.  Training (and fp32 I/O) stay on the scan: the backward twin is not written yet.
+# mixer to the A-shared scan.  fp32 I/O stays on the scan; the backward twin is ssd_bwd below.
 SSD_MFMA = os.environ.get("DIFFMA_SSD_MFMA", "1") == "1"
 
 

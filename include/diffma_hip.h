@@ -380,14 +380,14 @@ typedef struct {
 int dm_colsum_f32(const dm_colsum_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Mamba-2 SSD core, single chunk, on the matrix pipe (forward; the no-grad path of --use-mamba2).  Replaces the scan stage of
+ * Mamba-2 SSD core, single chunk, on the matrix pipe (forward of --use-mamba2 with 16-bit activations).  Replaces the scan stage of
  * mamba_split_conv1d_scan_combined (block/mamba2.py:392-410) for chunk_size >= seqlen:
  *     dt = softplus(dt_raw + dt_bias[h]);  s = A[h] * cumsum(dt);  G = (C B^T) .* exp(s_l - s_i) [i <= l];
  *     y = (G diag(dt)) x + D[h] x;   out = y * silu(z)
  * x: [nseq][L][nheads*64] view (the conv output's x columns), B, C: [nseq][L][16] views (16-byte aligned rows), all after the
  * conv, per gathered sequence; dt_raw: [batch][L][nheads] and z: [batch][L][nheads*64] in TOKEN order, read through z_row_index;
  * out: [nseq][rows][nheads*64], step l stored at row out_row_index[dir][l].  16-bit I/O, headdim 64, d_state 16,
- * seqlen <= 224: dm_ssd_fwd_supported() tells; everything else (and training) takes the A-shared scan.
+ * seqlen <= 224: dm_ssd_fwd_supported() tells; everything else takes the A-shared scan.  dm_ssd_bwd below is its backward.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
     int32_t nseq, batch_per_dir, seqlen, nheads, headdim, dstate;
