@@ -360,15 +360,17 @@ def main():
     if rank == 0:
         ksum = timer.summary()
         kernel_source = "events on the launch stream over the timed region"
-        if not ksum and args.mode == "sample":          # hipGraph replay: launches are not visible to the host-side timer
+        if args.mode == "sample" and args.graph:         # hipGraph replay: the denoiser's launches are not visible to the host-side timer
+            timer = hip_ops.KernelTimer()                 # (only the fused sampler kernel outside the graph was): time 2 eager steps instead
             hip_ops.set_timer(timer)
             for _ in range(2):
                 t_ = torch.full((B,), 5, device=dev, dtype=torch.long)
                 with torch.no_grad(), torch.autocast("cuda", dtype=amp, enabled=amp is not None):
-                    model(batch["z"], t_, **kw)
+                    (sdiff.p_sample if args.sampler == "ddpm250" else sdiff.ddim_sample)(model.forward, state["x"], t_, clip_denoised=False, model_kwargs=kw)
+            torch.cuda.synchronize()
             hip_ops.set_timer(None)
             ksum = timer.summary()
-            kernel_source = "2 eager forwards after the timed region (the timed steps replay a hipGraph)"
+            kernel_source = "2 eager sampler steps after the timed region (the timed steps replay a hipGraph)"
         elif not ksum:                                   # graphed training step: time the kernels of 2 eager steps instead
             hip_ops.set_timer(timer)
             for _ in range(2):

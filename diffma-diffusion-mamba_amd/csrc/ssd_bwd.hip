@@ -47,11 +47,11 @@ constexpr int SB_CS = SB_BS + SB_TAB * 32;        // C   [224][16]
 constexpr int SB_BT = SB_CS + SB_TAB * 32;        // B^T [16][196]
 constexpr int SB_CT = SB_BT + 16 * SB_TPITCH;     // C^T [16][196] + 64 B of zeros
 constexpr int SB_TABS = SB_CT + 16 * SB_TPITCH + 64;   // fp32 tables [T_NTAB][224]
-enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_TMP0, T_TMP1, T_NTAB };
+enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_NTAB };
 constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // int tables: z rows, dout rows
 constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 4;         // 8 waves x [8][SB_STG] fp32
 constexpr int SB_RED = SB_STAGE + 8 * 8 * SB_STG * 4;     // block-reduction scratch [2][8] fp32
-constexpr int SB_LDS_BYTES = SB_RED + 64;
+constexpr int SB_LDS_BYTES = SB_RED + 96;              // [dA | dD partials per wave | wave totals of the prefix sums]
 static_assert(SB_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS writes visible to its other lanes
@@ -74,6 +74,22 @@ __device__ __forceinline__ ssd_u32x4 t_frag(const uint8_t* base, int prow, int k
     const ssd_u32x2 lo = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2);
     const ssd_u32x2 hi = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2 + 16);
     return (ssd_u32x4){lo.x, lo.y, hi.x, hi.y};
+}
+
+// Inclusive prefix sum over threads 0..255 of the workgroup (one value each; the other threads pass 0 and ignore the result):
+// six shuffle steps inside each wave, one barrier to pass the wave totals on.  Every thread of the workgroup must call it.
+__device__ __forceinline__ float block_prefix_sum(float v, int lane, int w, float* wtot) {
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const float t = __shfl_up(v, off);
+        if (lane >= off) v += t;
+    }
+    if (lane == WAVE - 1) wtot[w] = v;
+    __syncthreads();
+    float base = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) base += (j < w) ? wtot[j] : 0.0f;
+    return v + base;
 }
 
 template <typename T>
@@ -121,8 +137,9 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     float* const dbc_part = p.dBC_part + ((int64_t)s * H + h) * L * 32;
 
     // ---- phase 0: per-position scalars -----------------------------------------------------------------------------------
-    if (tid < SB_TAB) {
-        float dtv = 0.0f, sg = 0.0f;
+    float dtv = 0.0f;
+    {
+        float sg = 0.0f;
         int zr = 0, orow = 0;
         if (tid < L) {
             zr = zidx ? zidx[tid] : tid;
@@ -131,26 +148,19 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
             dtv = softplus_f(raw);
             sg = (raw > 20.0f) ? 1.0f : sigmoid_f(raw);                            // d softplus / d raw (identity above 20)
         }
-        DT[tid] = dtv;
-        SIG[tid] = sg;
-        tab[T_TMP0 * SB_TAB + tid] = dtv;
-        zi[tid] = zr;
-        oi[tid] = orow;
-    }
-    __syncthreads();
-    int cur = 0;
-    for (int off = 1; off < SB_TAB; off <<= 1) {                                  // inclusive prefix sum of dt (Hillis-Steele)
         if (tid < SB_TAB) {
-            const float* src = tab + (T_TMP0 + cur) * SB_TAB;
-            tab[(T_TMP0 + (cur ^ 1)) * SB_TAB + tid] = src[tid] + (tid >= off ? src[tid - off] : 0.0f);
+            DT[tid] = dtv;
+            SIG[tid] = sg;
+            zi[tid] = zr;
+            oi[tid] = orow;
         }
-        __syncthreads();
-        cur ^= 1;
     }
-    if (tid < SB_TAB) {
-        const float c = tab[(T_TMP0 + cur) * SB_TAB + tid];
-        CUM[tid] = c;
-        S2[tid] = a2 * c;                                                         // log2-domain log-decay
+    {
+        const float c = block_prefix_sum(dtv, lane, w, red);                       // cumsum(dt)
+        if (tid < SB_TAB) {
+            CUM[tid] = c;
+            S2[tid] = a2 * c;                                                     // log2-domain log-decay
+        }
     }
     __syncthreads();
     if (tid < SB_TAB) {
@@ -459,34 +469,24 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     }
     __syncthreads();
 
-    // ---- phase 3: d dt, dA, dD ------------------------------------------------------------------------------------------------
+    // ---- phase 3: d dt, dA, dD (thread t works on position 223 - t: the cumulative sum of d s runs from the end) ----------------
+    const int pos = SB_TAB - 1 - tid;
+    const bool live = tid < SB_TAB && pos < L;
     float csv = 0.0f, dsv = 0.0f;
-    if (tid < L) {
-        csv = CSV[tid];
-        dsv = RS[tid] - DT[tid] * csv;                                            // d s_l
+    if (live) {
+        csv = CSV[pos];
+        dsv = RS[pos] - DT[pos] * csv;                                            // d s_l
     }
+    const float rc = block_prefix_sum(dsv, lane, w, red + 16);                    // sum_{l >= pos} d s_l
     {
-        const float a = wave_sum_dpp(dsv * ((tid < L) ? CUM[tid] : 0.0f)), d = wave_sum_dpp(dD_acc);
+        const float a = wave_sum_dpp(live ? dsv * CUM[pos] : 0.0f), d = wave_sum_dpp(dD_acc);
         if (lane == 0) {
             red[w] = a;
             red[8 + w] = d;
         }
     }
-    if (tid < SB_TAB) tab[T_TMP0 * SB_TAB + tid] = dsv;
+    if (live) p.ddt[((int64_t)s * L + zi[pos]) * H + h] = (csv + Ah * rc) * SIG[pos];
     __syncthreads();
-    cur = 0;
-    for (int off = 1; off < SB_TAB; off <<= 1) {                                  // reverse inclusive cumulative sum of ds
-        if (tid < SB_TAB) {
-            const float* src = tab + (T_TMP0 + cur) * SB_TAB;
-            tab[(T_TMP0 + (cur ^ 1)) * SB_TAB + tid] = src[tid] + (tid + off < SB_TAB ? src[tid + off] : 0.0f);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-    if (tid < L) {
-        const float ddt = csv + Ah * tab[(T_TMP0 + cur) * SB_TAB + tid];
-        p.ddt[((int64_t)s * L + zi[tid]) * H + h] = ddt * SIG[tid];
-    }
     if (tid == 0) {
         float a = 0.0f, d = 0.0f;
 #pragma unroll
