@@ -9,7 +9,7 @@
 //     V  = R .* G .* M:      ds_l = sum_i V[l,i] dt_i - dt_l sum_q V[q,l];   d dt_i = sum_l V[l,i] + A * sum_{l >= i} ds_l
 //     dA = sum_l ds_l cumsum(dt)_l;    d raw = d dt * sigmoid(raw + bias)
 // Nothing is saved by the forward.  One 512-thread workgroup per (sequence, head) holds X, gY (row-major AND transposed), B, C
-// (both ways) in 123 KB of LDS and walks the 28 causal 32 x 32 tile pairs twice, concurrently:
+// (both ways) in 158 KB of LDS (one workgroup per CU) and walks the 28 causal 32 x 32 tile pairs twice, concurrently:
 //   * waves 0-3, "T" orientation (score tile with keys as rows, queries as columns): its accumulator registers are the
 //     A-operand of  Y += W X  and  dC += dG B  -- they own query tiles {6}, {5,0}, {4,1}, {3,2} (7 pairs each);
 //   * waves 4-7, "N" orientation (queries as rows, keys as columns): accumulators are the A-operand of  dX += W^T gY  and
@@ -17,8 +17,9 @@
 // Each orientation computes its own G (1 MFMA) and R (4 MFMAs, K = 64) per pair, applies the decay (factorised per tile pair as in
 // the forward: alpha_l * delta(lt,it) * gamma_i off the diagonal, element-wise exp + causal mask on the 7 diagonal tiles), feeds
 // the rounded tiles straight back (no LDS round trip), and accumulates the row sums (T) / column sums (N) of V that d dt and dA
-// need.  22 MFMAs and ~100 VALU per pair and orientation.  Tile epilogues turn 8 rows at a time through a 2 KB staging tile so
-// every global access is a 16-byte piece of a row.  The final d dt / dA reverse cumulative sum runs on the whole workgroup.
+// need.  11 MFMAs and ~135 VALU per pair and orientation.  Tile epilogues turn 8 rows at a time through a 2 KB staging tile so
+// every global access is a 16-byte piece of a row.  The final d dt / dA reverse cumulative sum runs on the whole workgroup
+// (shuffle scans inside the waves, one barrier).  Measured and profiled: DESIGN.md section 3 (K6b), profiles/r02_pmc_scan_kernels.txt.
 #include "dm_common.h"
 #include "ssd_common.h"
 
