@@ -707,7 +707,10 @@ SSD_MFMA_BWD = os.environ.get("DIFFMA_SSD_MFMA_BWD", "1") == "1"
 
 
 def ssd_bwd_supported(x, L, headdim, dstate, views=()):
-    if not (SSD_MFMA and SSD_MFMA_BWD and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)):
+    """The autograd node asks this before it commits the forward to the matrix pipe.  bf16 only: the kernel rounds its score and
+    gradient tiles to the I/O dtype, and under fp16 autocast the GradScaler's 2^16 loss scale would push those tiles past the
+    fp16 range (the scan pair keeps every intermediate in fp32) -- the fp16 instantiation exists and is parity-tested unscaled."""
+    if not (SSD_MFMA and SSD_MFMA_BWD and x.is_cuda and x.dtype == torch.bfloat16):
         return False
     for v in views:
         if v is not None and (v.data_ptr() % 16 or v.stride(-1) != 1 or any(st % 8 for st in v.stride()[:-1])):
