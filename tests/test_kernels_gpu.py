@@ -732,3 +732,58 @@ def test_ssd_bwd_mfma_matches_oracle_autograd(gpu, dtype, Bsz, L, H, ndir):
     close(dA.sum(0), A_r.grad, "dA")
     close(dD.sum(0), D_r.grad, "dD")
     close(ddt.sum((0, 1)), b_r.grad, "d dt_bias")
+
+
+def test_ssd_matrix_pipe_agrees_with_the_scan_pair_at_full_size(gpu):
+    """BASELINE config 4 at full size (DiffMa-XL/2 --use-mamba2, batch 64: 192 gathered sequences x 16 heads x 196 steps): the
+    matrix-pipe pair (K6 / K6b) against the A-shared scan pair (K1 / K2) -- two independent HIP implementations of the same
+    operator, each pinned to the oracle at small sizes -- on every output; exercises the grid-level indexing (head column
+    offsets, per-direction row tables, batch_per_dir sharing of z and dt) that the small cases cannot."""
+    from diffma_amd import hip_ops
+
+    B, L, H, P, N, ndir = 64, 196, 16, 64, 16, 3
+    S, Din = ndir * B, H * P
+    dt_ = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(77)
+    xBC = torch.randn(S, L, Din + 2 * N, generator=g).to(dt_).to(gpu)
+    dt_tok = (torch.randn(B, L, H, generator=g) * 0.7 - 1.0).to(dt_).to(gpu)
+    z = torch.randn(B, L, Din, generator=g).to(dt_).to(gpu)
+    dout = torch.randn(S, L, Din, generator=g).to(dt_).to(gpu)
+    A_h = -(torch.rand(H, generator=g) * 6 + 0.3).to(gpu)
+    D_h, b_h = torch.randn(H, generator=g).to(gpu), (torch.randn(H, generator=g) * 0.5).to(gpu)
+    idx = torch.stack([torch.arange(L), torch.randperm(L, generator=g), torch.randperm(L, generator=g)]).int().to(gpu)
+    x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
+
+    y1 = hip_ops.ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, b_h, z_row_index=idx, out_row_index=idx, batch_per_dir=B)
+    dxBC1 = torch.empty_like(xBC)
+    _, dz1, dbc1, ddt1, dA1, dD1 = hip_ops.ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, b_h, z_row_index=idx, out_row_index=idx,
+                                                   batch_per_dir=B, dx_out=dxBC1[..., :Din])
+    idx64 = idx.long()
+    inv = torch.argsort(idx64, dim=1)
+    delta = torch.stack([dt_tok[:, idx64[k]] for k in range(ndir)]).reshape(S, L, H, 1).expand(S, L, H, P).reshape(S, L, Din).contiguous()
+    A = A_h.repeat_interleave(P)[:, None].expand(Din, N).contiguous()
+    Dp, bp = D_h.repeat_interleave(P), b_h.repeat_interleave(P)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, dt_, gpu)
+    y2 = hip_ops.scan_fwd(x, delta, A, Bm, Cm, Dp, z, bp, True, z_row_index=idx, out_row_index=idx, batch_per_dir=B, ckpt=ckpt, a_shared=True)
+    dxBC2 = torch.empty_like(xBC)
+    _, ddelta, dz2, _, _, dA2, dD2, dbias2 = hip_ops.scan_bwd(x, delta, A, Bm, Cm, Dp, z, bp, dout, ckpt, True, z_row_index=idx, out_row_index=idx,
+                                                             batch_per_dir=B, dout_per_seq=True, du_out=dxBC2[..., :Din], a_shared=True,
+                                                             dbc_out=dxBC2[..., Din:])
+    torch.cuda.synchronize()
+
+    def agree(a, b, what, tol=2e-2):
+        a, b = a.float(), b.float()
+        err = (a - b).norm() / b.norm().clamp_min(1e-30)
+        assert torch.isfinite(a).all() and err <= tol, (what, float(err))
+
+    agree(y1, y2, "out")
+    agree(dxBC1[..., :Din], dxBC2[..., :Din], "dx")
+    agree(dz1, dz2, "dz")
+    agree(dbc1.sum(1), dxBC2[..., Din:], "dB | dC")
+    # the scan pair returns d(delta) per channel in scan order: sum the head's channels and put the rows in token order
+    ddt2 = ddelta.float().view(ndir, B, L, H, P).sum(-1)
+    ddt2 = torch.stack([ddt2[k][:, inv[k]] for k in range(ndir)]).reshape(S, L, H)
+    agree(ddt1, ddt2, "d raw dt")
+    agree(dA1.sum(0), dA2.float().view(H, P * N).sum(-1), "dA")
+    agree(dD1.sum(0), dD2.float().view(H, P).sum(-1), "dD")
+    agree(ddt1.sum((0, 1)), dbias2.float().view(H, P).sum(-1), "d dt_bias")
