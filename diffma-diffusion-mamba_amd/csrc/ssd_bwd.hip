@@ -52,7 +52,7 @@ enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_NTAB };
 constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // int tables: z rows, dout rows
 constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 4;         // 8 waves x [8][SB_STG] fp32
 constexpr int SB_RED = SB_STAGE + 8 * 8 * SB_STG * 4;     // block-reduction scratch [2][8] fp32
-constexpr int SB_LDS_BYTES = SB_RED + 96;              // [dA | dD partials per wave | wave totals of the prefix sums]
+constexpr int SB_LDS_BYTES = SB_RED + 128;             // [dA | dD | dbias partials per wave | wave totals of the prefix sums]
 static_assert(SB_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS writes visible to its other lanes
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     const int sl_x = (int)p.x_sl * ES, sl_B = (int)p.B_sl * ES, sl_C = (int)p.C_sl * ES, sl_z = (int)p.z_sl * ES;
     const int sl_do = (int)p.do_sl * ES, sl_dx = (int)p.dx_sl * ES, sl_dz = (int)p.dz_sl * ES;
     const int hb = h * 64 * ES;                                                   // byte offset of the head's columns in a row
-    float* const dbc_part = p.dBC_part + ((int64_t)s * H + h) * L * 32;
+    float* const dbc_part = p.dBC_part + ((int64_t)h * p.nseq + s) * L * 32;          // head-major: the caller's sum over heads is a column sum
 
     // ---- phase 0: per-position scalars -----------------------------------------------------------------------------------
     float dtv = 0.0f;
@@ -478,25 +478,23 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
         csv = CSV[pos];
         dsv = RS[pos] - DT[pos] * csv;                                            // d s_l
     }
-    const float rc = block_prefix_sum(dsv, lane, w, red + 16);                    // sum_{l >= pos} d s_l
+    const float rc = block_prefix_sum(dsv, lane, w, red + 24);                    // sum_{l >= pos} d s_l
+    const float draw = live ? (csv + Ah * rc) * SIG[pos] : 0.0f;                  // d(raw dt) through softplus
     {
-        const float a = wave_sum_dpp(live ? dsv * CUM[pos] : 0.0f), d = wave_sum_dpp(dD_acc);
+        const float a = wave_sum_dpp(live ? dsv * CUM[pos] : 0.0f), d = wave_sum_dpp(dD_acc), b = wave_sum_dpp(draw);
         if (lane == 0) {
             red[w] = a;
             red[8 + w] = d;
+            red[16 + w] = b;
         }
     }
-    if (live) p.ddt[((int64_t)s * L + zi[pos]) * H + h] = (csv + Ah * rc) * SIG[pos];
+    if (live) p.ddt[((int64_t)s * L + zi[pos]) * H + h] = draw;
     __syncthreads();
-    if (tid == 0) {
-        float a = 0.0f, d = 0.0f;
+    if (tid < 3) {                                                                // dA | dD | d dt_bias partial sums of this (sequence, head)
+        float t = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            a += red[k];
-            d += red[8 + k];
-        }
-        p.dA_part[(int64_t)s * H + h] = a;
-        p.dD_part[(int64_t)s * H + h] = d;
+        for (int k = 0; k < 8; ++k) t += red[8 * tid + k];
+        p.dAD_part[((int64_t)tid * p.nseq + s) * H + h] = t;
     }
 }
 
@@ -510,7 +508,7 @@ extern "C" int dm_ssd_bwd(const dm_ssd_bwd_args* args, void* stream) {
     using namespace dm;
     if (!args) { set_error("dm_ssd_bwd: null args"); return DM_ERR_ARG; }
     const dm_ssd_bwd_args& a = *args;
-    if (!a.x || !a.B || !a.C || !a.dt || !a.dout || !a.A || !a.dx || !a.dBC_part || !a.ddt || !a.dA_part || !a.dD_part) {
+    if (!a.x || !a.B || !a.C || !a.dt || !a.dout || !a.A || !a.dx || !a.dBC_part || !a.ddt || !a.dAD_part) {
         set_error("dm_ssd_bwd: null tensor pointer"); return DM_ERR_ARG;
     }
     if ((a.z == nullptr) != (a.dz == nullptr)) { set_error("dm_ssd_bwd: z and dz go together"); return DM_ERR_ARG; }

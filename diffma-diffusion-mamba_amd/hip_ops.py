@@ -721,8 +721,8 @@ def ssd_bwd_supported(x, L, headdim, dstate, views=()):
 def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None, out_row_index=None, batch_per_dir=0, dx_out=None):
     """Operands as ssd_fwd; dout: [S, L, H*64] gradient of the gated output, step l read at row out_row_index[dir][l].
     Returns (dx [S, L, H*64] scan order (dx_out view if given), dz [S, L, H*64] token order per direction,
-    dBC_part fp32 [S, H, L, 32] (dB | dC per head), ddt fp32 [S, L, H] raw-dt gradient in token order per direction,
-    dA_part, dD_part fp32 [S, H])."""
+    dBC fp32 [S, L, 32] (dB | dC, the per-head partial rows already summed), ddt fp32 [S, L, H] raw-dt gradient in token order per
+    direction, dAD fp32 [3, H]: dA | dD | d dt_bias summed over the sequences)."""
     _require_gpu(x, Bm, Cm, dt_tok, z, dout)
     S, L, Din = x.shape
     H = A_h.shape[0]
@@ -730,10 +730,9 @@ def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None
     assert dout.shape == (S, L, Din) and dout.stride(2) == 1 and dout.dtype == x.dtype
     dx = dx_out if dx_out is not None else torch.empty((S, L, Din), dtype=x.dtype, device=x.device)
     dz = torch.empty((S, L, Din), dtype=x.dtype, device=x.device) if z is not None else None
-    dbc = torch.empty((S, H, L, 32), dtype=torch.float32, device=x.device)
+    dbc = torch.empty((H, S, L, 32), dtype=torch.float32, device=x.device)       # head-major partial rows: summed by one column sum
     ddt = torch.empty((S, L, H), dtype=torch.float32, device=x.device)
-    dA = torch.empty((S, H), dtype=torch.float32, device=x.device)
-    dD = torch.empty((S, H), dtype=torch.float32, device=x.device)
+    dad = torch.empty((3, S, H), dtype=torch.float32, device=x.device)
     A32, D32, b32 = _f32c(A_h), _f32c(D_h), _f32c(dt_bias_h)
     a = dm_ssd_bwd_args()
     a.nseq, a.batch_per_dir, a.seqlen, a.nheads, a.headdim, a.dstate = S, batch_per_dir, L, H, 64, 16
@@ -742,7 +741,7 @@ def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None
     a.A, a.D, a.dt_bias = _ptr(A32), _ptr(D32), _ptr(b32)
     a.z_row_index, a.out_row_index = _ptr(z_row_index), _ptr(out_row_index)
     a.dx, a.dz = _ptr(dx), _ptr(dz)
-    a.dBC_part, a.ddt, a.dA_part, a.dD_part = _ptr(dbc), _ptr(ddt), _ptr(dA), _ptr(dD)
+    a.dBC_part, a.ddt, a.dAD_part = _ptr(dbc), _ptr(ddt), _ptr(dad)
     a.x_ss, a.x_sl = x.stride(0), x.stride(1)
     a.B_ss, a.B_sl = Bm.stride(0), Bm.stride(1)
     a.C_ss, a.C_sl = Cm.stride(0), Cm.stride(1)
@@ -754,4 +753,5 @@ def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None
     a.dx_ss, a.dx_sl = dx.stride(0), dx.stride(1)
     es = x.element_size()
     _launch("dm_ssd_bwd", a, x, (6 if z is not None else 3) * S * L * Din * es + 2 * S * L * 16 * es + S * H * L * 32 * 4)
-    return dx, dz, dbc, ddt, dA, dD
+    dbc_sum = colsum(dbc.view(H, S * L * 32)).view(S, L, 32) if H > 1 else dbc.view(S, L, 32)
+    return dx, dz, dbc_sum, ddt, dad.sum(1)

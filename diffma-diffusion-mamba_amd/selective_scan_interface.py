@@ -465,10 +465,10 @@ class _SpiralSSDFn(torch.autograd.Function):
         dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
         dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
-        _, dzs, dbc_part, ddt, dA_part, dD_part = hip_ops.ssd_bwd(
+        _, dzs, dbc, ddt, dad = hip_ops.ssd_bwd(
             x, Bm, Cm, zxbcdt[..., Din + Cx:], zxbcdt[..., :Din], dyd.view(S, L, Din), A_h, D_h, dt_bias_h, z_row_index=scan_index,
             out_row_index=scan_index, batch_per_dir=Bsz, dx_out=dxBC[..., :Din])
-        dxBC[..., Din:].copy_(dbc_part.sum(1))                                        # heads share B and C: dB | dC in their xBC columns
+        dxBC[..., Din:].copy_(dbc)                                                    # dB | dC (summed over the heads) in their xBC columns
         dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(zxbcdt[..., Din:Din + Cx], conv_w, conv_b, dxBC, row_index=scan_index,
                                                                ndir=ndir, silu=True)                              # token order
         dzx = torch.empty_like(zxbcdt)
@@ -477,9 +477,8 @@ class _SpiralSSDFn(torch.autograd.Function):
         ddt4 = ddt.view(ndir, Bsz, L, H)                                              # already in token order, raw-dt gradient: add the directions
         ddt_tok = ddt4[0] if ndir == 1 else ddt4.sum(0)
         dzx[..., Din + Cx:].copy_(ddt_tok)
-        dbias_h = ddt_tok.sum((0, 1))
         return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
-                dbias_h.to(bias_dt), dA_part.sum(0).to(A_dt), dD_part.sum(0).to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
+                dad[2].to(bias_dt), dad[0].to(A_dt), dad[1].to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
 
 
 def spiral_ssd(zxbcdt, conv_w, conv_b, dt_bias, A, D, norm_w, eps, scan_index, scan_index_inv, d_inner, d_state):

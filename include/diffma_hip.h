@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 16
+#define DM_ABI_VERSION 17
 
 typedef enum {
     DM_OK = 0,
@@ -414,9 +414,10 @@ int dm_ssd_fwd_supported(int seqlen, int headdim, int dstate, int io_dtype);
  *         sequence, as dm_rmsnorm_merge_bwd leaves it);
  *   dx:   [nseq][L][..] view (scan order; the x columns of the conv output's gradient);
  *   dz:   [nseq][rows][nheads*64], step l written at row z_row_index[dir][l] (token order per direction: dm_token_merge sums them);
- *   dBC_part: fp32 [nseq][nheads][L][32]  per-head partial rows  dB (0..15) | dC (16..31) -- the caller sums over heads;
+ *   dBC_part: fp32 [nheads][nseq][L][32]  per-head partial rows  dB (0..15) | dC (16..31) -- the caller sums over heads
+ *         (head-major: one dm_colsum_f32 over nheads rows);
  *   ddt:  fp32 [nseq][rows][nheads], gradient of the RAW per-head dt (through softplus), step l at row z_row_index[dir][l];
- *   dA_part, dD_part: fp32 [nseq][nheads] partial sums (the caller sums over sequences; d dt_bias = sum of ddt).
+ *   dAD_part: fp32 [3][nseq][nheads] partial sums of dA | dD | d dt_bias per (sequence, head) -- the caller sums over sequences.
  * 16-bit I/O, headdim 64, d_state 16, seqlen <= 196, 16-byte aligned rows: dm_ssd_bwd_supported() tells.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -426,7 +427,7 @@ typedef struct {
     const float *A, *D, *dt_bias;       /* [nheads] fp32 (D, dt_bias may be NULL) */
     const int32_t *z_row_index, *out_row_index;
     void *dx, *dz;
-    float *dBC_part, *ddt, *dA_part, *dD_part;
+    float *dBC_part, *ddt, *dAD_part;
     int64_t x_ss, x_sl;
     int64_t B_ss, B_sl;
     int64_t C_ss, C_sl;
