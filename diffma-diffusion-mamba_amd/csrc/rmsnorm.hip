@@ -10,7 +10,7 @@
 namespace dm {
 
 constexpr int RMS_WAVES = 4;
-constexpr int RMS_ROWS_PER_BLOCK = 32;
+constexpr int RMS_ROWS_PER_BLOCK = 16;     // backward: rows per workgroup = rows per weight-gradient partial row (4 per wave)
 
 __device__ __forceinline__ float rms_wave_sum(float v) { return wave_sum_dpp(v); }
 
@@ -123,12 +123,8 @@ __global__ __launch_bounds__(64 * RMS_WAVES) void rmsnorm_merge_bwd_kernel(const
                 for (int j = 0; j < 4; ++j) g[it][j] = 0.f;
             }
         }
-        for (int k = 0; k < p.nslab; ++k) {
+        auto load_slab = [&](int k, float (&v)[NIT][4]) {
             const T* yr = (const T*)p.y + (int64_t)k * p.y_ss + r * p.y_sr;
-            T* dyr = (T*)p.dy + (int64_t)k * p.dy_ss + r * p.dy_sr;
-            const float rstd = p.rstd[(int64_t)k * p.rows + r];
-            float v[NIT][4];
-            float dot = 0.f;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = (it * 64 + lane) * 4;
@@ -138,9 +134,23 @@ __global__ __launch_bounds__(64 * RMS_WAVES) void rmsnorm_merge_bwd_kernel(const
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[it][j] = 0.f;
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) dot += g[it][j] * w[it][j] * v[it][j];
             }
+        };
+        float vn[NIT][4];
+        load_slab(0, vn);
+        for (int k = 0; k < p.nslab; ++k) {
+            T* dyr = (T*)p.dy + (int64_t)k * p.dy_ss + r * p.dy_sr;
+            const float rstd = p.rstd[(int64_t)k * p.rows + r];
+            float v[NIT][4];
+            float dot = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[it][j] = vn[it][j];
+                    dot += g[it][j] * w[it][j] * v[it][j];
+                }
+            if (k + 1 < p.nslab) load_slab(k + 1, vn);       // the next slab's row is in flight under this one's reduction
             const float coef = rms_wave_sum(dot) * rstd * rstd * rstd / (float)C;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
