@@ -494,7 +494,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
         float t = 0.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[8 * tid + k];
-        p.dAD_part[((int64_t)tid * p.nseq + s) * H + h] = t;
+        p.dAD_part[((int64_t)s * 3 + tid) * H + h] = t;
     }
 }
 

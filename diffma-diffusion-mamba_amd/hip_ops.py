@@ -289,10 +289,13 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
             colsum(dbias) if dbias is not None else None)
 
 
-def colsum(x):
+_COLSUM_SMALL = os.environ.get("DIFFMA_COLSUM_SMALL", "1") == "1"
+
+
+def colsum(x, small=False):
     """x [R, C] fp32 contiguous -> [C] = x.sum(0) (dm_colsum_f32: ATen's outer-dimension reduction is 4x off HBM speed here)."""
     R, C = x.shape
-    if C % 4 != 0 or not x.is_contiguous() or x.dtype != torch.float32:
+    if C % 4 != 0 or not x.is_contiguous() or x.dtype != torch.float32 or (small and not _COLSUM_SMALL):
         return x.sum(0)
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
     a = dm_colsum_args()
@@ -468,7 +471,8 @@ def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=Tru
     a.do_ss, a.do_sl, a.do_sd = dout.stride()
     a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
     _launch("dm_gather_conv1d_bwd", a, x, 3 * ndir * Bsz * L * Dm * x.element_size())
-    return dx, dw.sum(dim=(0, 1)), db.sum(dim=(0, 1))
+    # partial rows -> one column sum each (ATen's reduction of these shapes takes ~21 us per call, dm_colsum_f32 ~5)
+    return dx, colsum(dw.view(ndir * Bsz * nchunk, Dm * W), True).view(Dm, W), colsum(db.view(ndir * Bsz * nchunk, Dm), True)
 
 
 def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
@@ -621,7 +625,7 @@ def rmsnorm_merge_bwd(y, weight, eps, rstd, dout):
     a.rstd, a.dout, a.dy, a.dw_part = _ptr(rstd), _ptr(dout), _ptr(dy), _ptr(part)
     a.dout_sr, a.dy_ss, a.dy_sr = C, dy.stride(0), C
     _launch("dm_rmsnorm_merge_bwd", a, y, (2 * K + 1) * Bsz * L * C * y.element_size())
-    return dy, part.sum(0)
+    return dy, colsum(part, True)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -732,7 +736,7 @@ def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None
     dz = torch.empty((S, L, Din), dtype=x.dtype, device=x.device) if z is not None else None
     dbc = torch.empty((H, S, L, 32), dtype=torch.float32, device=x.device)       # head-major partial rows: summed by one column sum
     ddt = torch.empty((S, L, H), dtype=torch.float32, device=x.device)
-    dad = torch.empty((3, S, H), dtype=torch.float32, device=x.device)
+    dad = torch.empty((S, 3, H), dtype=torch.float32, device=x.device)
     A32, D32, b32 = _f32c(A_h), _f32c(D_h), _f32c(dt_bias_h)
     a = dm_ssd_bwd_args()
     a.nseq, a.batch_per_dir, a.seqlen, a.nheads, a.headdim, a.dstate = S, batch_per_dir, L, H, 64, 16
@@ -754,4 +758,4 @@ def ssd_bwd(x, Bm, Cm, dt_tok, z, dout, A_h, D_h, dt_bias_h, *, z_row_index=None
     es = x.element_size()
     _launch("dm_ssd_bwd", a, x, (6 if z is not None else 3) * S * L * Din * es + 2 * S * L * 16 * es + S * H * L * 32 * 4)
     dbc_sum = colsum(dbc.view(H, S * L * 32)).view(S, L, 32) if H > 1 else dbc.view(S, L, 32)
-    return dx, dz, dbc_sum, ddt, dad.sum(1)
+    return dx, dz, dbc_sum, ddt, colsum(dad.view(S, 3 * H), True).view(3, H)

@@ -417,7 +417,8 @@ int dm_ssd_fwd_supported(int seqlen, int headdim, int dstate, int io_dtype);
  *   dBC_part: fp32 [nheads][nseq][L][32]  per-head partial rows  dB (0..15) | dC (16..31) -- the caller sums over heads
  *         (head-major: one dm_colsum_f32 over nheads rows);
  *   ddt:  fp32 [nseq][rows][nheads], gradient of the RAW per-head dt (through softplus), step l at row z_row_index[dir][l];
- *   dAD_part: fp32 [3][nseq][nheads] partial sums of dA | dD | d dt_bias per (sequence, head) -- the caller sums over sequences.
+ *   dAD_part: fp32 [nseq][3][nheads] partial sums of dA | dD | d dt_bias per (sequence, head) -- the caller sums over sequences
+ *         (one dm_colsum_f32 over nseq rows when 3 * nheads is a multiple of 4).
  * 16-bit I/O, headdim 64, d_state 16, seqlen <= 196, 16-byte aligned rows: dm_ssd_bwd_supported() tells.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
