@@ -304,3 +304,28 @@ def test_fused_diffusion_step_matches_golden_and_generic_path(gpu, monkeypatch, 
             b = d.p_sample(fake, x_t * 3, t0, clip_denoised=clip)
             torch.testing.assert_close(a["sample"], b["sample"].float(), **tol)
             torch.testing.assert_close(a["pred_xstart"], b["pred_xstart"].float(), **tol)
+
+
+@pytest.mark.parametrize("compression", ["none", "bf16"])
+def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
+    """The driver's multi-GPU launch contract on the one GPU a test box has: `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1 ...` with the DDP / RCCL path forced on (BENCH_FORCE_DDP=1: process group over nccl = RCCL, the shared
+    `train.wrap_ddp` settings, optionally 16-bit gradient buckets), barrier-bracketed timing, one JSON line on rank 0."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DDP="1", DIFFMA_GRAD_COMPRESSION=compression, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "4",
+           "--cpu-steps", "0", "--no-extras"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["world_size_seen_by_rccl"] == 1 and d["config"]["parallelism"].startswith("dp1")
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["kernel"].startswith("dm_selective_scan")
