@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (sample mode: the denoiser call; train mode, 1 GPU: the whole optimisation step -- for small batches where the eager step is host-bound)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (sample mode: the denoiser call; train mode: the whole optimisation step, with several ranks as two graphs around one gradient all-reduce -- for small batches where the eager step is host-bound)")
     return ap.parse_args()
 
 
@@ -281,16 +281,23 @@ def main():
     if args.mode == "train":
         ema = copy.deepcopy(model).requires_grad_(False)
         net = model
-        if world > 1 or force_ddp:
+        graph_train = args.graph
+        data_parallel = world > 1 or force_ddp
+        if data_parallel and not graph_train:
             from diffma_amd.train import wrap_ddp                        # the SAME wrapper (buckets, static_graph, hooks) as train.py
             net = wrap_ddp(model, dev, grad_compression=os.environ.get("DIFFMA_GRAD_COMPRESSION", "none"))
-        graph_train = args.graph and world == 1 and not force_ddp          # DDP keeps the eager step (bucketed all-reduce)
+        elif data_parallel:                                              # graphed step: two graphs around ONE all-reduce (graphed.py), no DDP wrapper
+            with torch.no_grad():
+                for t_ in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t_.data, 0)
+                for pe, pm in zip(ema.parameters(), model.parameters()):
+                    pe.copy_(pm)
         opt = torch.optim.AdamW(net.parameters(), lr=1e-4, weight_decay=0, fused=True, capturable=graph_train)
         net.train()
         if graph_train:
             from diffma_amd.graphed import GraphedTrainStep
             gstep = GraphedTrainStep(model, ema, opt, diffusion, batch["z"], torch.zeros(B, device=dev, dtype=torch.long),
-                                     kw["y"], kw["y2"], kw["w"], autocast_dtype=amp, ema_decay=0.999)
+                                     kw["y"], kw["y2"], kw["w"], autocast_dtype=amp, ema_decay=0.999, split=True if data_parallel else None)
 
             def step():
                 t = torch.randint(0, diffusion.num_timesteps, (B,), device=dev)
@@ -422,7 +429,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
             "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
-            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1) else "") if args.mode == "train"
+            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1 and not force_ddp) else (", step replayed from two hipGraphs around one gradient all-reduce" if args.graph else "")) if args.mode == "train"
                        else f"{args.model} {'p_sample step (250-step respaced DDPM)' if args.sampler == 'ddpm250' else 'ddim_sample step (50-step DDIM)'}, batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},

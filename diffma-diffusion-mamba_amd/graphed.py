@@ -11,6 +11,18 @@ from __future__ import annotations
 import torch
 
 
+def _capture_mode(device):
+    """With a process group alive (multi-rank sampling / training), RCCL's watchdog thread polls its work events (hipEventQuery) at
+    any time; under the default "global" capture mode such a call from ANOTHER thread invalidates this thread's capture
+    ("operation not permitted when stream is capturing", seen as an abort of `bench.py --graph` under torch.distributed.run).  Let
+    the collectives issued so far retire, then capture in thread-local mode."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize(device)
+        return "thread_local"
+    return "global"
+
+
 class GraphedDenoiser:
     """Callable with the model's signature `(x, t, y=, y2=, w=)`; replays a captured graph.
 
@@ -46,7 +58,7 @@ class GraphedDenoiser:
                     self._run()
             torch.cuda.current_stream(x.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(self.graph):
+            with torch.no_grad(), torch.cuda.graph(self.graph, capture_error_mode=_capture_mode(x.device)):
                 self.sout = self._run()
 
     def _run(self):
@@ -83,13 +95,21 @@ class GraphedTrainStep:
     across steps, the C-ABI launches are asynchronous and allocation-free and the diffusion tables live on the device,
     so the step is captured once (after eager warm-up iterations that also settle the GEMM table) and replayed with the
     batch copied into static buffers.  The noise of `training_losses` is drawn inside the graph (PyTorch's graph-safe
-    Philox offsets advance per replay).  Construction leaves weights, EMA and optimizer state as it found them.  Single
-    process only: under DDP the bucketed all-reduce keeps the eager step.
+    Philox offsets advance per replay).  Construction leaves weights, EMA and optimizer state as it found them.
 
-    step(z, t, y, y2, w) -> loss (a 0-d device tensor that is overwritten by the next replay).
+    Data parallel (`process_group` with more than one rank, or `split=True`): the step is TWO graphs with the gradient
+    all-reduce between them -- graph 1 = forward + backward + the gradients flattened into one buffer, then ONE eager
+    `all_reduce(AVG)` over RCCL (nothing of the collective is captured), graph 2 = gradients back into place, fused AdamW, EMA.
+    This is the reference's own `brain.yaml` case (global batch 8 on 8 GPUs = ONE sample per GPU), where the eager DDP step is
+    bound by the host's launch rate on every rank; the all-reduce is not overlapped with the backward (it follows a ~10-20 ms
+    replay instead of hiding in a 55 ms host-bound step).  The caller keeps the ranks' weights identical at entry (train.py
+    broadcasts them) and does NOT wrap the model in DistributedDataParallel.
+
+    step(z, t, y, y2, w) -> loss (a 0-d device tensor that is overwritten by the next replay; the local rank's loss).
     """
 
-    def __init__(self, model, ema, optimizer, diffusion, z, t, y, y2, w, autocast_dtype=None, ema_decay=0.9999, warmup=3):
+    def __init__(self, model, ema, optimizer, diffusion, z, t, y, y2, w, autocast_dtype=None, ema_decay=0.9999, warmup=3,
+                 process_group=None, split=None):
         assert z.is_cuda, "graph capture needs a ROCm device"
         for g in optimizer.param_groups:
             if not g.get("capturable", False):
@@ -107,17 +127,37 @@ class GraphedTrainStep:
             p_snap = [p.detach().clone() for p in model.parameters()]
             e_snap = [p.detach().clone() for p in self._ep]
             o_snap = {id(v): v.detach().clone() for st in optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
+        import torch.distributed as dist
+        self.pg = process_group
+        nranks = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.split = bool(split) if split is not None else nranks > 1
+        if self.split and not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("the two-graph (data-parallel) step needs an initialised process group")
+        self._gp = [p for p in model.parameters() if p.requires_grad]
         with torch.cuda.device(z.device):
             side = torch.cuda.Stream(device=z.device)
             side.wait_stream(torch.cuda.current_stream(z.device))
             with torch.cuda.stream(side):
                 for _ in range(warmup):                   # lazy inits, GEMM solution lookups, optimizer state allocation
-                    self._step()
+                    if self.split:
+                        self._fwd_bwd()
+                        self._all_reduce()
+                        self._update()
+                    else:
+                        self._step()
             torch.cuda.current_stream(z.device).wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             self.opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(self.graph):
-                self.sloss = self._step()
+            mode = _capture_mode(z.device)
+            if self.split:
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):       # gradients are allocated inside the graph's pool and stay attached
+                    self.sloss = self._fwd_bwd()
+                self.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
+                    self._update()
+            else:
+                with torch.cuda.graph(self.graph, capture_error_mode=mode):
+                    self.sloss = self._step()
         with torch.no_grad():
             for p, q in zip(model.parameters(), p_snap):
                 p.copy_(q)
@@ -140,6 +180,36 @@ class GraphedTrainStep:
         self.opt.zero_grad(set_to_none=True)
         return loss.detach()
 
+    # ---- the data-parallel form: graph 1 | all-reduce | graph 2 ----------------------------------------------------------
+    def _fwd_bwd(self):
+        with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+            loss = self.diffusion.training_losses(self.model, self.sz, self.st, dict(y=self.sy, y2=self.sy2, w=self.sw))["loss"].mean()
+        loss.backward()
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._gp]
+        self.flat = torch.cat([g.reshape(-1).float() for g in grads])          # one buffer = one collective
+        return loss.detach()
+
+    def _all_reduce(self):
+        import torch.distributed as dist
+        dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
+
+    def _update(self):
+        with torch.no_grad():
+            off = 0
+            for p in self._gp:                              # the averaged gradients back into the tensors the optimizer reads
+                n = p.numel()
+                g = self.flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.to(p.dtype).clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self.opt.step()
+        if self.ema is not None:
+            with torch.no_grad():
+                torch._foreach_mul_(self._ep, self.decay)
+                torch._foreach_add_(self._ep, self._mp, alpha=1 - self.decay)
+
     def step(self, z, t, y, y2, w):
         self.sz.copy_(z)
         self.st.copy_(t)
@@ -148,6 +218,9 @@ class GraphedTrainStep:
         self.sw.copy_(w)
         with torch.cuda.device(self.sz.device):
             self.graph.replay()
+            if self.split:
+                self._all_reduce()
+                self.graph2.replay()
         # a replayed optimizer updates A_log without bumping its version counter: drop the mixers' no-grad cache of -exp(A_log)
         for m in self._mixers:
             m.__dict__.pop("_A_cache", None)

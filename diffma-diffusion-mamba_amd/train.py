@@ -161,11 +161,15 @@ def main(args):
         ema = deepcopy(model).to(device)
     requires_grad(ema, False)
     model = model.to(device)
-    # graph_train: replay the whole optimisation step from a hipGraph (single process; pays off below ~100 samples per GPU,
+    # graph_train: replay the whole optimisation step from a hipGraph (pays off below ~100 samples per GPU,
     # where the eager step is bound by the host's launch rate -- e.g. the reference's own global_batch_size of 8)
-    use_graph = bool(args.get("graph_train", False)) and world == 1 and device.type == "cuda" and int(args.accumulation_steps) == 1
+    use_graph = bool(args.get("graph_train", False)) and device.type == "cuda" and int(args.accumulation_steps) == 1
     if use_graph:
-        ddp = model                                  # one process: no reducer hooks inside the captured backward
+        ddp = model                                  # no reducer hooks inside the captured backward: with several ranks the graphed
+        if world > 1:                                # step all-reduces the flattened gradients itself (graphed.GraphedTrainStep)
+            with torch.no_grad():
+                for t_ in list(model.parameters()) + list(model.buffers()):
+                    dist.broadcast(t_.data, 0)       # what the DDP constructor would have done: every rank starts from rank 0's weights
     else:
         ddp = wrap_ddp(model, device, grad_compression=str(args.get("grad_compression", "none")))
     diffusion = create_diffusion(timestep_respacing="")
@@ -201,7 +205,8 @@ def main(args):
             if use_graph:
                 if graphed is None:
                     from .graphed import GraphedTrainStep
-                    graphed = GraphedTrainStep(model, ema, opt, diffusion, z, t, y, y2, w, autocast_dtype=amp, ema_decay=0.999)
+                    graphed = GraphedTrainStep(model, ema, opt, diffusion, z, t, y, y2, w, autocast_dtype=amp, ema_decay=0.999,
+                                               split=True if os.environ.get("DIFFMA_GRAPH_SPLIT") == "1" else None)
                 loss = graphed.step(z, t, y, y2, w)             # forward, backward, AdamW and EMA in one replay
                 train_steps += 1
                 log_steps += 1

@@ -150,11 +150,11 @@ def _dist_env(monkeypatch, port):
         monkeypatch.setenv(k, v)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16", "bf16-graph", "bf16-gradcomp"])
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16", "bf16-graph", "bf16-graph-split", "bf16-gradcomp"])
 def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
     """train.py:main (reference train.py:90-311) on one GPU through RCCL + DDP: DiffMa-S/2 (196 tokens) on synthetic latents,
-    bf16 autocast (default), fp32, the reference's fp16 + GradScaler mode, the graphed step, and the opt-in bf16 gradient
-    all-reduce.  Checks: step count, the reference-format checkpoint, finite weights that moved, EMA = its recurrence."""
+    bf16 autocast (default), fp32, the reference's fp16 + GradScaler mode, the graphed step (one graph, and the data-parallel
+    form: two graphs around one RCCL all-reduce of the flattened gradients), and the opt-in bf16 gradient all-reduce.  Checks: step count, the reference-format checkpoint, finite weights that moved, EMA = its recurrence."""
     import socket
 
     from diffma_amd import train as train_mod
@@ -166,11 +166,13 @@ def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
     port = s.getsockname()[1]
     s.close()
     _dist_env(monkeypatch, port)
+    if mode == "bf16-graph-split":
+        monkeypatch.setenv("DIFFMA_GRAPH_SPLIT", "1")
     cfg = Config(model="DiffMa-S/2", image_size=224, dt_rank=16, d_state=16, global_batch_size=4, global_seed=0, lr=1e-4, lr_=1e-4,
                  epochs=1, accumulation_steps=1, log_every=1, ckpt_every=3, results_dir=str(tmp_path / "res"),
                  init_from_pretrain_ckpt=False, pretrain_ckpt_path="", init_train_steps=0, synthetic=True, synthetic_samples=64,
                  max_steps=3, autocast=mode != "fp32", amp_dtype="fp16" if mode == "fp16" else "bf16",
-                 graph_train=mode == "bf16-graph", grad_compression="bf16" if mode == "bf16-gradcomp" else "none")
+                 graph_train=mode.startswith("bf16-graph"), grad_compression="bf16" if mode == "bf16-gradcomp" else "none")
     assert train_mod.main(cfg) == 3
     ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith("0000003.pt")]
     assert len(ck) == 1
@@ -306,20 +308,28 @@ def test_fused_diffusion_step_matches_golden_and_generic_path(gpu, monkeypatch, 
             torch.testing.assert_close(a["pred_xstart"], b["pred_xstart"].float(), **tol)
 
 
-@pytest.mark.parametrize("compression", ["none", "bf16"])
+@pytest.mark.parametrize("compression", ["none", "bf16", "graph"])
 def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
     """The driver's multi-GPU launch contract on the one GPU a test box has: `python -m torch.distributed.run --nproc-per-node 1
     bench.py --gpus 1 ...` with the DDP / RCCL path forced on (BENCH_FORCE_DDP=1: process group over nccl = RCCL, the shared
-    `train.wrap_ddp` settings, optionally 16-bit gradient buckets), barrier-bracketed timing, one JSON line on rank 0."""
+    `train.wrap_ddp` settings, optionally 16-bit gradient buckets; "graph": `--graph`, the step replayed from two hipGraphs around one
+    all-reduce instead of the DDP wrapper), barrier-bracketed timing, one JSON line on rank 0."""
     import json
     import subprocess
     import sys
 
+    import socket
+
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BENCH_FORCE_DDP="1", DIFFMA_GRAD_COMPRESSION=compression, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]                    # a free port per case: a fixed one can still be in TIME_WAIT from the previous case
+    sk.close()
+    graph = compression == "graph"
+    env = dict(os.environ, BENCH_FORCE_DDP="1", DIFFMA_GRAD_COMPRESSION="none" if graph else compression, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29653", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "4",
-           "--cpu-steps", "0", "--no-extras"]
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-per-gpu", "4",
+           "--cpu-steps", "0", "--no-extras"] + (["--graph"] if graph else [])
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -329,3 +339,53 @@ def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
     assert d["config"]["world_size_seen_by_rccl"] == 1 and d["config"]["parallelism"].startswith("dp1")
     assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["roofline"]["kernel"].startswith("dm_selective_scan")
+    assert ("two hipGraphs" in d["config"]["workload"]) == graph
+
+
+def test_graphed_train_step_two_graphs_equal_one_graph(gpu, monkeypatch):
+    """graphed.GraphedTrainStep in its data-parallel form (graph 1: forward + backward + flattened gradients | eager
+    all_reduce(AVG) over RCCL | graph 2: AdamW + EMA) on a one-rank process group must reproduce the single-graph step bit for
+    bit: same loss sequence, same weights, same EMA after 6 steps."""
+    import copy
+    import socket
+
+    import torch.distributed as dist
+
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.graphed import GraphedTrainStep
+    from diffma_amd.model import DiffMa
+
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        _dist_env(monkeypatch, port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    torch.manual_seed(21)
+    net0 = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=2, d_state=16).to(gpu)
+    with torch.no_grad():
+        for p in net0.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.02)
+    B = 4
+    mk = lambda *sh: torch.randn(*sh, device=gpu)
+    x, y, y2, w = mk(B, 4, 8, 8), mk(B, 64), mk(B, 16, 64), torch.sigmoid(mk(B, 16, 1))
+    d = create_diffusion("")
+
+    def run(split):
+        torch.manual_seed(11)
+        net = copy.deepcopy(net0).train()
+        ema = copy.deepcopy(net).requires_grad_(False)
+        opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=0, fused=True, capturable=True)
+        gs = GraphedTrainStep(net, ema, opt, d, x, torch.zeros(B, device=gpu, dtype=torch.long), y, y2, w, ema_decay=0.9, warmup=2, split=split)
+        assert gs.split == split
+        tg = torch.Generator(device=gpu).manual_seed(5)
+        losses = [float(gs.step(x, torch.randint(0, d.num_timesteps, (B,), device=gpu, generator=tg), y, y2, w)) for _ in range(6)]
+        return losses, [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()]
+
+    l1, p1, e1 = run(False)
+    l2, p2, e2 = run(True)
+    assert all(l == l for l in l1) and l1 == l2, (l1, l2)
+    for a, b in zip(p1 + e1, p2 + e2):
+        torch.testing.assert_close(a, b, rtol=0, atol=0)
