@@ -5,6 +5,8 @@
 #   tools/launch_8gpu.sh sample [N] [sample.py args...]     replicas: every rank samples its own shard, no collective
 # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver only supports dmabuf IPC (RCCL fails with hipIpcGetMemHandle otherwise).
 # DIFFMA_GRAD_COMPRESSION=bf16 (bench) / --grad-compression bf16 (train): opt-in 16-bit gradient all-reduce.
+# Small per-GPU batches (the reference's brain.yaml: 1 sample per GPU): `bench ... --batch-per-gpu 1 --graph` / `train ... --graph-train`
+# replay the step from two hipGraphs around one gradient all-reduce instead of the host-bound eager DDP step.
 set -e
 MODE=${1:-bench}; N=${2:-8}; shift 2 || true
 cd "$(dirname "$0")/.."
