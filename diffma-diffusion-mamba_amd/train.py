@@ -281,7 +281,7 @@ def cli(argv=None):
     p.add_argument("--max-steps", type=int, default=None)
     p.add_argument("--grad-compression", default=None, choices=["none", "bf16", "fp16"],
                    help="all-reduce 16-bit copies of the DDP gradient buckets (opt-in; default none = fp32 like the reference)")
-    p.add_argument("--graph-train", action="store_true", help="replay the whole optimisation step from a hipGraph (1 GPU; for small batches)")
+    p.add_argument("--graph-train", action="store_true", help="replay the whole optimisation step from a hipGraph (for small batches; with several ranks: two graphs around one gradient all-reduce)")
     p.add_argument("--config", type=str, required=True)
     a = p.parse_args(argv)
     over = {k: v for k, v in vars(a).items() if v is not None and k != "config"}
