@@ -8,16 +8,20 @@
 //     dG = R .* M .* dt_i:   dC = dG B,  dB = dG^T C    (partial per head; B and C are shared by the heads)
 //     V  = R .* G .* M:      ds_l = sum_i V[l,i] dt_i - dt_l sum_q V[q,l];   d dt_i = sum_l V[l,i] + A * sum_{l >= i} ds_l
 //     dA = sum_l ds_l cumsum(dt)_l;    d raw = d dt * sigmoid(raw + bias)
-// Nothing is saved by the forward.  One 512-thread workgroup per (sequence, head) holds X, gY (row-major AND transposed), B, C
-// (both ways) in 158 KB of LDS (one workgroup per CU) and walks the 28 causal 32 x 32 tile pairs twice, concurrently:
-//   * waves 0-3, "T" orientation (score tile with keys as rows, queries as columns): its accumulator registers are the
-//     A-operand of  Y += W X  and  dC += dG B  -- they own query tiles {6}, {5,0}, {4,1}, {3,2} (7 pairs each);
-//   * waves 4-7, "N" orientation (queries as rows, keys as columns): accumulators are the A-operand of  dX += W^T gY  and
-//     dB += dG^T C  -- they own key tiles {0}, {1,6}, {2,5}, {3,4}.
+// Nothing is saved by the forward.  One 256-thread workgroup per (sequence, head) holds X, gY, B, C row-major in 79 KB of LDS
+// (TWO workgroups per CU: the load / compute / store phases of different heads overlap) and walks the 28 causal 32 x 32 tile
+// pairs twice, concurrently:
+//   * waves 0-1, "T" orientation (score tile with keys as rows, queries as columns): its accumulator registers are the
+//     A-operand of  Y += W X  and  dC += dG B  -- they own query tiles {6,3,2,0} and {5,4,1} (15 / 13 pairs);
+//   * waves 2-3, "N" orientation (queries as rows, keys as columns): accumulators are the A-operand of  dX += W^T gY  and
+//     dB += dG^T C  -- they own key tiles {0,3,4,6} and {1,2,5}.
 // Each orientation computes its own G (1 MFMA) and R (4 MFMAs, K = 64) per pair, applies the decay (factorised per tile pair as in
 // the forward: alpha_l * delta(lt,it) * gamma_i off the diagonal, element-wise exp + causal mask on the 7 diagonal tiles), feeds
 // the rounded tiles straight back (no LDS round trip), and accumulates the row sums (T) / column sums (N) of V that d dt and dA
-// need.  11 MFMAs and ~135 VALU per pair and orientation.  Tile epilogues turn 8 rows at a time through a 2 KB staging tile so
+// need.  The second products contract over sequence positions, i.e. they want X / gY / B / C with positions in the K slots: instead
+// of transposed LDS copies, the row-major fragments already loaded for R (rows = positions, K = channels) are multiplied by 0/1
+// selector fragments -- the result X[position][channel] comes out in accumulator layout, which IS that B-operand layout (exact:
+// one product by 1.0 per element).  16 MFMAs and ~160 VALU per pair and orientation.  Tile epilogues turn 8 rows at a time through a 2 KB staging tile so
 // every global access is a 16-byte piece of a row.  The final d dt / dA reverse cumulative sum runs on the whole workgroup
 // (shuffle scans inside the waves, one barrier).  Measured and profiled: DESIGN.md section 3 (K6b), profiles/r02_pmc_scan_kernels.txt.
 #include "dm_common.h"
@@ -25,35 +29,27 @@
 
 namespace dm {
 
-typedef uint32_t ssd_u32x2 __attribute__((ext_vector_type(2)));
-
 constexpr int SB_MAXL = 196;                      // longest sequence
 constexpr int SB_TILE = 32, SB_MAXT = 7;
 constexpr int SB_TAB = SB_TILE * SB_MAXT;         // 224 tile-rounded positions
-constexpr int SB_TPITCH = SB_MAXL * 2;            // bytes per row of a transposed array: 98 dwords = 2 mod 32 banks
-constexpr int SB_THREADS = 512;
+constexpr int SB_ROWS = SB_MAXL + 1;              // LDS rows of the operand arrays: row 196 is all zeros, every position past it aliases to it
+constexpr int SB_WAVES = 4;
+constexpr int SB_THREADS = 64 * SB_WAVES;
 constexpr int SB_STG = 68;                        // dwords per staging-tile row (64 + 4)
 
-// LDS map (byte offsets)
-// Row-major arrays hold all 224 tile-rounded rows, zero past the sequence, so fragment addresses are affine in the tile index
-// (no clamps, no selects).  The transposed arrays hold 196 positions per row: a fragment of the last tile that runs past position
-// 195 reads the head of the NEXT row / array -- finite 16-bit data that only ever meets exact zeros in the other operand (the
-// score-tile entries of positions >= L are 0 because dt, B, C and gY are zero there); a zero pad follows the last array.
-constexpr int SB_XS = 0;                          // X   [224][64]  16-byte chunks XOR-swizzled by (row & 7)
-constexpr int SB_GS = SB_XS + SB_TAB * 128;       // gY  [224][64]  same layout
-constexpr int SB_XT = SB_GS + SB_TAB * 128;       // X^T [64][196]
-constexpr int SB_GT = SB_XT + 64 * SB_TPITCH;     // gY^T[64][196]
-constexpr int SB_BS = SB_GT + 64 * SB_TPITCH;     // B   [224][16]
-constexpr int SB_CS = SB_BS + SB_TAB * 32;        // C   [224][16]
-constexpr int SB_BT = SB_CS + SB_TAB * 32;        // B^T [16][196]
-constexpr int SB_CT = SB_BT + 16 * SB_TPITCH;     // C^T [16][196] + 64 B of zeros
-constexpr int SB_TABS = SB_CT + 16 * SB_TPITCH + 64;   // fp32 tables [T_NTAB][224]
+// LDS map (byte offsets); rows [L, 196] of the operand arrays are zero
+constexpr int SB_XS = 0;                          // X   [197][64]  16-byte chunks XOR-swizzled by (row & 7)
+constexpr int SB_GS = SB_XS + SB_ROWS * 128;      // gY  [197][64]  same layout
+constexpr int SB_BS = SB_GS + SB_ROWS * 128;      // B   [197][16]
+constexpr int SB_CS = SB_BS + SB_ROWS * 32;       // C   [197][16]
+constexpr int SB_TABS = SB_CS + SB_ROWS * 32;     // fp32 tables [T_NTAB][224]
 enum { T_DT, T_CUM, T_S2, T_ALPHA, T_GAM, T_GDT, T_SIG, T_RS, T_CS, T_NTAB };
-constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // int tables: z rows, dout rows
-constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 4;         // 8 waves x [8][SB_STG] fp32
-constexpr int SB_RED = SB_STAGE + 8 * 8 * SB_STG * 4;     // block-reduction scratch [2][8] fp32
-constexpr int SB_LDS_BYTES = SB_RED + 128;             // [dA | dD | dbias partials per wave | wave totals of the prefix sums]
-static_assert(SB_LDS_BYTES <= 160 * 1024, "LDS budget");
+constexpr int SB_IDX = SB_TABS + T_NTAB * SB_TAB * 4;     // uint16 tables: z rows, dout rows
+constexpr int SB_STAGE = SB_IDX + 2 * SB_TAB * 2;         // 4 waves x [8][SB_STG] fp32
+constexpr int SB_RED = SB_STAGE + SB_WAVES * 8 * SB_STG * 4;   // block-reduction scratch
+constexpr int SB_LDS_BYTES = SB_RED + 128;
+static_assert(SB_LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+static_assert(SB_TABS % 16 == 0 && SB_STAGE % 16 == 0, "16-byte aligned LDS arrays");
 
 __device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS writes visible to its other lanes
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -61,24 +57,36 @@ __device__ __forceinline__ void wave_lds_sync() {         // make one wave's LDS
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 8 consecutive columns (chunk) of a row of the swizzled [224][64] arrays, as an MFMA operand fragment
+// 8 consecutive columns (chunk) of a row of the swizzled [197][64] arrays, as an MFMA operand fragment (rows >= 196: the zero row)
 __device__ __forceinline__ ssd_u32x4 row_frag(const uint8_t* base, int row, int chunk) {
-    return *reinterpret_cast<const ssd_u32x4*>(base + row * 128 + ((chunk ^ (row & 7)) << 4));
+    const int rc = row < SB_MAXL ? row : SB_MAXL;
+    return *reinterpret_cast<const ssd_u32x4*>(base + rc * 128 + ((chunk ^ (rc & 7)) << 4));
 }
 // 8 states of a B / C row
 __device__ __forceinline__ ssd_u32x4 bc_frag(const uint8_t* base, int row, int kh) {
-    return *reinterpret_cast<const ssd_u32x4*>(base + row * 32 + kh * 16);
+    const int rc = row < SB_MAXL ? row : SB_MAXL;
+    return *reinterpret_cast<const ssd_u32x4*>(base + rc * 32 + kh * 16);
 }
-// B-operand of a product whose K index runs over sequence positions in ACCUMULATOR order: slots 0-3 = positions k0..k0+3, slots
-// 4-7 = k0+8..k0+11 of row `prow` of a transposed array (k0 = 32 tile + 4 kh + 16 ks)
-__device__ __forceinline__ ssd_u32x4 t_frag(const uint8_t* base, int prow, int k0) {
-    const ssd_u32x2 lo = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2);
-    const ssd_u32x2 hi = *reinterpret_cast<const ssd_u32x2*>(base + prow * SB_TPITCH + k0 * 2 + 16);
-    return (ssd_u32x4){lo.x, lo.y, hi.x, hi.y};
+// One-hot selector fragment: slot e (0..7) of this lane holds 1.0, every other slot 0 (e outside 0..7: all zero)
+template <typename T>
+__device__ __forceinline__ ssd_u32x4 one_hot(int e) {
+    constexpr uint32_t ONE = std::is_same<T, bf16_t>::value ? 0x3F80u : 0x3C00u;
+    const uint32_t v = (e & 1) ? (ONE << 16) : ONE;
+    const int d = e >> 1;
+    const bool ok = e >= 0 && e < 8;
+    return (ssd_u32x4){(ok && d == 0) ? v : 0u, (ok && d == 1) ? v : 0u, (ok && d == 2) ? v : 0u, (ok && d == 3) ? v : 0u};
+}
+// accumulator tile -> the two K-step fragments (8 positions each, accumulator order) of a 16-bit B-operand
+template <typename O>
+__device__ __forceinline__ void acc_to_frags(const f32x16& d, ssd_u32x4 (&f)[2]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+        f[ks] = (ssd_u32x4){O::pack(d[8 * ks], d[8 * ks + 1]), O::pack(d[8 * ks + 2], d[8 * ks + 3]), O::pack(d[8 * ks + 4], d[8 * ks + 5]),
+                            O::pack(d[8 * ks + 6], d[8 * ks + 7])};
 }
 
-// Inclusive prefix sum over threads 0..255 of the workgroup (one value each; the other threads pass 0 and ignore the result):
-// six shuffle steps inside each wave, one barrier to pass the wave totals on.  Every thread of the workgroup must call it.
+// Inclusive prefix sum over the workgroup's 256 threads (one value each): six shuffle steps inside each wave, one barrier to pass
+// the wave totals on.  Every thread of the workgroup must call it.
 __device__ __forceinline__ float block_prefix_sum(float v, int lane, int w, float* wtot) {
 #pragma unroll
     for (int off = 1; off < WAVE; off <<= 1) {
@@ -89,12 +97,12 @@ __device__ __forceinline__ float block_prefix_sum(float v, int lane, int w, floa
     __syncthreads();
     float base = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) base += (j < w) ? wtot[j] : 0.0f;
+    for (int j = 0; j < SB_WAVES - 1; ++j) base += (j < w) ? wtot[j] : 0.0f;
     return v + base;
 }
 
 template <typename T>
-__global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_args p) {
+__global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void ssd_bwd_kernel(const dm_ssd_bwd_args p) {
     using O = ssd_ops<T>;
     constexpr int ES = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -108,8 +116,8 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     float* const SIG = tab + T_SIG * SB_TAB;
     float* const RS = tab + T_RS * SB_TAB;
     float* const CSV = tab + T_CS * SB_TAB;
-    int* const zi = reinterpret_cast<int*>(lds + SB_IDX);
-    int* const oi = zi + SB_TAB;
+    uint16_t* const zi = reinterpret_cast<uint16_t*>(lds + SB_IDX);
+    uint16_t* const oi = zi + SB_TAB;
     float* const red = reinterpret_cast<float*>(lds + SB_RED);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,7 +128,6 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     const int dir = s / bpd;
     const int sb = s - dir * bpd;
     const int nt_l = (L + SB_TILE - 1) / SB_TILE;
-    const int LR = SB_TILE * nt_l;                                                // LDS rows to fill (zeros past L)
     const int32_t* __restrict__ zidx = p.z_row_index ? p.z_row_index + (int64_t)dir * L : nullptr;
     const int32_t* __restrict__ oidx = p.out_row_index ? p.out_row_index + (int64_t)dir * L : nullptr;
     const float Ah = p.A[h], a2 = Ah * LOG2E, Dh = p.D ? p.D[h] : 0.0f, bias = p.dt_bias ? p.dt_bias[h] : 0.0f;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     const int hb = h * 64 * ES;                                                   // byte offset of the head's columns in a row
     float* const dbc_part = p.dBC_part + ((int64_t)h * p.nseq + s) * L * 32;          // head-major: the caller's sum over heads is a column sum
 
-    // ---- phase 0: per-position scalars -----------------------------------------------------------------------------------
+    // ---- phase 0: per-position scalars (thread t <-> position t) ----------------------------------------------------------------
     float dtv = 0.0f;
     {
         float sg = 0.0f;
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
         if (tid < SB_TAB) {
             DT[tid] = dtv;
             SIG[tid] = sg;
-            zi[tid] = zr;
-            oi[tid] = orow;
+            zi[tid] = (uint16_t)zr;
+            oi[tid] = (uint16_t)orow;
         }
     }
     {
@@ -175,29 +182,31 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     }
     auto m_of = [&](int t) -> float { return t ? S2[SB_TILE * t - 1] : 0.0f; };   // log-decay just before tile t
 
-    // ---- phase 1: X, gY = dout .* silu(z) (both ways), B, C (both ways) into LDS; wave w moves 16-byte chunk w of every row ----
+    // ---- phase 1: X, gY = dout .* silu(z), B, C into LDS; wave w moves the 16-byte chunks w and w + 4 of every row --------------
     float dD_acc = 0.0f;
-    {
-        const int cb = hb + w * 16;
+#pragma unroll 1
+    for (int m = 0; m < 2; ++m) {
+        const int ck = w + 4 * m;
+        const int cb = hb + ck * 16;
         ssd_u32x4 xq4[4], dq4[4], zq4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {                                             // all 12 loads in flight before the first use
+        for (int j = 0; j < 4; ++j) {                                             // 12 loads in flight before the first use
             const int r = lane + 64 * j;
             const int rc = r < L ? r : L - 1;
             const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, rc * sl_x + cb, 0, 0);
-            const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[rc] * sl_do + cb, 0, 0);
+            const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, (int)oi[rc] * sl_do + cb, 0, 0);
             xq4[j] = (ssd_u32x4){xq[0], xq[1], xq[2], xq[3]};
             dq4[j] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
             zq4[j] = (ssd_u32x4){0u, 0u, 0u, 0u};
             if (p.z) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[rc] * sl_z + cb, 0, 0);
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, (int)zi[rc] * sl_z + cb, 0, 0);
                 zq4[j] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = lane + 64 * j;
-            if (r < LR) {
+            if (r < SB_ROWS) {
                 ssd_u32x4 xv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
                 if (r < L) {
                     const ssd_u32x4 xq = xq4[j], dq = dq4[j], zq = zq4[j];
@@ -213,21 +222,17 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                         gv[d] = O::pack(g0, g1);
                     }
                 }
-                const int so = r * 128 + ((w ^ (r & 7)) << 4);
+                const int so = r * 128 + ((ck ^ (r & 7)) << 4);
                 *reinterpret_cast<ssd_u32x4*>(lds + SB_XS + so) = xv;
                 *reinterpret_cast<ssd_u32x4*>(lds + SB_GS + so) = gv;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (r >= SB_MAXL) break;                                     // the transposed arrays end at position 195
-                    const int to = (8 * w + e) * SB_TPITCH + r * 2;
-                    *reinterpret_cast<uint16_t*>(lds + SB_XT + to) = (uint16_t)((e & 1) ? (xv[e >> 1] >> 16) : (xv[e >> 1] & 0xffffu));
-                    *reinterpret_cast<uint16_t*>(lds + SB_GT + to) = (uint16_t)((e & 1) ? (gv[e >> 1] >> 16) : (gv[e >> 1] & 0xffffu));
-                }
             }
         }
-        if (tid < 16) *reinterpret_cast<uint32_t*>(lds + SB_CT + 16 * SB_TPITCH + 4 * tid) = 0u;      // the pad behind the last transposed array
-        const int r = tid >> 1, hf = tid & 1;                                     // B / C: two 16-byte chunks per row
-        if (r < LR) {
+    }
+#pragma unroll 1
+    for (int i = 0; i < 2; ++i) {                                                 // B / C: two 16-byte chunks per row
+        const int e = tid + SB_THREADS * i;
+        const int r = e >> 1, hf = e & 1;
+        if (r < SB_ROWS) {
             ssd_u32x4 bv = {0u, 0u, 0u, 0u}, cv = {0u, 0u, 0u, 0u};
             if (r < L) {
                 const auto b = __builtin_amdgcn_raw_buffer_load_b128(r_B, r * sl_B + hf * 16, 0, 0);
@@ -237,13 +242,6 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
             }
             *reinterpret_cast<ssd_u32x4*>(lds + SB_BS + r * 32 + hf * 16) = bv;
             *reinterpret_cast<ssd_u32x4*>(lds + SB_CS + r * 32 + hf * 16) = cv;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (r >= SB_MAXL) break;
-                const int to = (8 * hf + e) * SB_TPITCH + r * 2;
-                *reinterpret_cast<uint16_t*>(lds + SB_BT + to) = (uint16_t)((e & 1) ? (bv[e >> 1] >> 16) : (bv[e >> 1] & 0xffffu));
-                *reinterpret_cast<uint16_t*>(lds + SB_CT + to) = (uint16_t)((e & 1) ? (cv[e >> 1] >> 16) : (cv[e >> 1] & 0xffffu));
-            }
         }
     }
     __syncthreads();
@@ -253,12 +251,19 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     const int row8 = lane >> 3, c8 = lane & 7;                                    // epilogue role: row of an 8-row slab, 16-byte chunk
     float* const stage = reinterpret_cast<float*>(lds + SB_STAGE) + w * 8 * SB_STG;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // selectors: a [positions x 64 channels] row-major fragment set times these = the 32-channel half nt in accumulator layout
+    // (K-step j of the half: channel 32 nt + q sits in slot q - 16 j - 8 kh); states likewise (16 of them, columns 16-31 empty)
+    const ssd_u32x4 selx[2] = {one_hot<T>(q - 8 * kh), one_hot<T>(q - 16 - 8 * kh)};
+    const ssd_u32x4 sel16 = one_hot<T>(q < 16 ? q - 8 * kh : -1);
+    // role of the wave: waves land on SIMD (w & 3); the T waves carry the heavier epilogue, so odd heads swap the roles and the two
+    // workgroups a CU holds put one T and one N wave on every SIMD
+    const int wr = (w + 2 * (int)(blockIdx.x & 1)) & 3;
 
-    if (w < 4) {
+    if (wr < 2) {
         // ===== T orientation: query tile lt; rows of the score tile = keys (registers), columns = queries (lanes) =====
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            const int lt = pass == 0 ? 6 - w : w - 1;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int lt = (wr == 0) ? (pass == 0 ? 6 : pass == 1 ? 3 : pass == 2 ? 2 : 0) : (pass == 0 ? 5 : pass == 1 ? 4 : pass == 2 ? 1 : -1);
             if (lt < 0 || lt >= nt_l) continue;
             const int ql = SB_TILE * lt + q;
             const ssd_u32x4 cB = bc_frag(lds + SB_CS, ql, kh);
@@ -274,8 +279,8 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                 zq4[r4] = (ssd_u32x4){0u, 0u, 0u, 0u};
                 dq4[r4] = (ssd_u32x4){0u, 0u, 0u, 0u};
                 if (p.dz) {
-                    const auto zq = __builtin_amdgcn_raw_buffer_load_b128(r_z, zi[lc] * sl_z + hb + c8 * 16, 0, 0);
-                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, oi[lc] * sl_do + hb + c8 * 16, 0, 0);
+                    const auto zq = __builtin_amdgcn_raw_buffer_load_b128(r_z, (int)zi[lc] * sl_z + hb + c8 * 16, 0, 0);
+                    const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, (int)oi[lc] * sl_do + hb + c8 * 16, 0, 0);
                     zq4[r4] = (ssd_u32x4){zq[0], zq[1], zq[2], zq[3]};
                     dq4[r4] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
                 }
@@ -285,10 +290,19 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
 #pragma unroll 1
             for (int it = 0; it <= lt; ++it) {
                 const int ki = SB_TILE * it + q;
-                f32x16 g = O::mfma(bc_frag(lds + SB_BS, ki, kh), cB, zero16);             // G[query][key]: keys 32it + 4kh + 8r4 + r in registers
+                const ssd_u32x4 bA = bc_frag(lds + SB_BS, ki, kh);
+                f32x16 g = O::mfma(bA, cB, zero16);                               // G[query][key]: keys 32it + 4kh + 8r4 + r in registers
+                ssd_u32x4 xA[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) xA[ks] = row_frag(lds + SB_XS, ki, 2 * ks + kh);
                 f32x16 rr = zero16;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(row_frag(lds + SB_XS, ki, 2 * ks + kh), gB[ks], rr);     // R = gY . X
+                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(xA[ks], gB[ks], rr);   // R = gY . X
+                // X and B of the key tile with the keys in the K slots (accumulator order): selector products
+                ssd_u32x4 xf0[2], xf1[2], bf[2];
+                acc_to_frags<O>(O::mfma(xA[1], selx[1], O::mfma(xA[0], selx[0], zero16)), xf0);
+                acc_to_frags<O>(O::mfma(xA[3], selx[1], O::mfma(xA[2], selx[0], zero16)), xf1);
+                acc_to_frags<O>(O::mfma(bA, sel16, zero16), bf);
                 const int kb = SB_TILE * it + 4 * kh;
                 float md[16];                                                     // M[query][key] * dt_key
                 if (it < lt) {
@@ -320,10 +334,9 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                 for (int ks = 0; ks < 2; ++ks) {
                     const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
                     const ssd_u32x4 df = {dp[4 * ks], dp[4 * ks + 1], dp[4 * ks + 2], dp[4 * ks + 3]};
-                    const int k0 = kb + 16 * ks;
-                    Y0 = O::mfma(wf, t_frag(lds + SB_XT, q, k0), Y0);
-                    Y1 = O::mfma(wf, t_frag(lds + SB_XT, 32 + q, k0), Y1);
-                    dC = O::mfma(df, t_frag(lds + SB_BT, q & 15, k0), dC);                    // (columns 16-31 of the result are unused copies)
+                    Y0 = O::mfma(wf, xf0[ks], Y0);
+                    Y1 = O::mfma(wf, xf1[ks], Y1);
+                    dC = O::mfma(df, bf[ks], dC);
                 }
             }
             rs += __shfl_xor(rs, 32);
@@ -374,26 +387,35 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
         }
     } else {
         // ===== N orientation: key tile it; rows of the score tile = queries (registers), columns = keys (lanes) =====
-        const int v = w - 4;
+        const int v = wr - 2;
 #pragma unroll 1
-        for (int pass = 0; pass < 2; ++pass) {
-            const int it = pass == 0 ? v : 7 - v;
-            if ((pass == 1 && v == 0) || it >= nt_l) continue;
+        for (int pass = 0; pass < 4; ++pass) {
+            const int it = (v == 0) ? (pass == 0 ? 0 : pass == 1 ? 3 : pass == 2 ? 4 : 6) : (pass == 0 ? 1 : pass == 1 ? 2 : pass == 2 ? 5 : -1);
+            if (it < 0 || it >= nt_l) continue;
             const int ki = SB_TILE * it + q;
+            const int kic = ki < SB_TAB ? ki : SB_TAB - 1;
             const ssd_u32x4 bB = bc_frag(lds + SB_BS, ki, kh);
             ssd_u32x4 xB[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) xB[ks] = row_frag(lds + SB_XS, ki, 2 * ks + kh);
-            const float dtk = DT[ki], gamk = GAM[ki], s2k = S2[ki], mnext = S2[SB_TILE * it + SB_TILE - 1];
+            const float dtk = DT[kic], gamk = GAM[kic], s2k = S2[kic], mnext = S2[SB_TILE * it + SB_TILE - 1];
             f32x16 X0 = zero16, X1 = zero16, dB = zero16;
             float cv = 0.0f;
 #pragma unroll 1
             for (int lt = it; lt < nt_l; ++lt) {
                 const int qrow = SB_TILE * lt + q;
-                f32x16 g = O::mfma(bc_frag(lds + SB_CS, qrow, kh), bB, zero16);           // G[query][key]: queries 32lt + 4kh + 8r4 + r in registers
+                const ssd_u32x4 cA = bc_frag(lds + SB_CS, qrow, kh);
+                f32x16 g = O::mfma(cA, bB, zero16);                               // G[query][key]: queries 32lt + 4kh + 8r4 + r in registers
+                ssd_u32x4 gA[4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) gA[ks] = row_frag(lds + SB_GS, qrow, 2 * ks + kh);
                 f32x16 rr = zero16;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(row_frag(lds + SB_GS, qrow, 2 * ks + kh), xB[ks], rr);
+                for (int ks = 0; ks < 4; ++ks) rr = O::mfma(gA[ks], xB[ks], rr);
+                ssd_u32x4 gf0[2], gf1[2], cf[2];                                   // gY and C of the query tile with the queries in the K slots
+                acc_to_frags<O>(O::mfma(gA[1], selx[1], O::mfma(gA[0], selx[0], zero16)), gf0);
+                acc_to_frags<O>(O::mfma(gA[3], selx[1], O::mfma(gA[2], selx[0], zero16)), gf1);
+                acc_to_frags<O>(O::mfma(cA, sel16, zero16), cf);
                 const int qb = SB_TILE * lt + 4 * kh;
                 float mf[16];                                                     // M[query][key] (without dt)
                 if (lt > it) {
@@ -424,10 +446,9 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
                 for (int ks = 0; ks < 2; ++ks) {
                     const ssd_u32x4 wf = {wp[4 * ks], wp[4 * ks + 1], wp[4 * ks + 2], wp[4 * ks + 3]};
                     const ssd_u32x4 df = {dp[4 * ks], dp[4 * ks + 1], dp[4 * ks + 2], dp[4 * ks + 3]};
-                    const int q0 = qb + 16 * ks;
-                    X0 = O::mfma(wf, t_frag(lds + SB_GT, q, q0), X0);
-                    X1 = O::mfma(wf, t_frag(lds + SB_GT, 32 + q, q0), X1);
-                    dB = O::mfma(df, t_frag(lds + SB_CT, q & 15, q0), dB);
+                    X0 = O::mfma(wf, gf0[ks], X0);
+                    X1 = O::mfma(wf, gf1[ks], X1);
+                    dB = O::mfma(df, cf[ks], dB);
                 }
             }
             cv += __shfl_xor(cv, 32);
@@ -493,7 +514,7 @@ __global__ __launch_bounds__(SB_THREADS) void ssd_bwd_kernel(const dm_ssd_bwd_ar
     if (tid < 3) {                                                                // dA | dD | d dt_bias partial sums of this (sequence, head)
         float t = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[8 * tid + k];
+        for (int k = 0; k < SB_WAVES; ++k) t += red[8 * tid + k];
         p.dAD_part[((int64_t)s * 3 + tid) * H + h] = t;
     }
 }

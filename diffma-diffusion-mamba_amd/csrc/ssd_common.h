@@ -15,10 +15,11 @@ template <> struct ssd_ops<bf16_t> {
     static __device__ __forceinline__ f32x16 mfma(const ssd_u32x4& a, const ssd_u32x4& b, const f32x16& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ssd_bf16x8, a), __builtin_bit_cast(ssd_bf16x8, b), c, 0, 0, 0);
     }
+    // v_cvt_pk_bf16_f32 through the compiler (NOT inline asm): the kernels convert MFMA results directly, and only an instruction
+    // the compiler knows gets the wait states an MFMA result needs before a VALU read (seen as 1 % garbage in K6b's selector tiles)
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
     static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-        return r;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){lo, hi}, b2));
     }
     static __device__ __forceinline__ float lo(uint32_t w) { return __uint_as_float(w << 16); }
     static __device__ __forceinline__ float hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
