@@ -27,6 +27,15 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
     return r & 0xffffu;
 }
 
+// The same instruction emitted by the compiler (vector fptrunc), for code whose schedule benefits from the compiler knowing
+// the instruction (K2: -2.5 %) or that converts MFMA results directly (an inline-asm reader of an MFMA result gets no wait
+// states).  K1 measures 5 % SLOWER with it, so both forms exist.
+typedef __bf16 dm_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float dm_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t dm_cvt_pk_bf16(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((dm_f32x2_t){lo, hi}, dm_bf16x2_t));
+}
+
 template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
@@ -73,6 +82,7 @@ template <> struct bio<float> {
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
     }
+    static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) { st(r, voff, soff, x); }
 };
 template <> struct bio<bf16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
@@ -82,6 +92,9 @@ template <> struct bio<bf16_t> {
         uint32_t b;
         asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(b) : "v"(x));       // low half is what store_b16 writes
         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b, r, voff, soff, 0);
+    }
+    static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) {      // conversion visible to the scheduler
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)dm_cvt_pk_bf16(x, x), r, voff, soff, 0);
     }
 };
 template <> struct bio<f16_t> {
@@ -97,6 +110,7 @@ template <> struct bio<f16_t> {
         __builtin_memcpy(&b, &h, 2);
         __builtin_amdgcn_raw_buffer_store_b16(b, r, voff, soff, 0);
     }
+    static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) { st(r, voff, soff, x); }
 };
 // NS consecutive elements (NS*sizeof(T) in {4, 8, 16} bytes use one wide load)
 template <typename T, int NS>

@@ -82,9 +82,7 @@ __device__ __forceinline__ void lane_group_reduce(float (&v)[M]) {
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    return dm_cvt_pk_bf16(lo, hi);
 }
 __device__ __forceinline__ void mfma_selectors(int lane, u32x4_t& a_lo, u32x4_t& a_hi) {
     const int i = lane & 15;
@@ -445,11 +443,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     dbias_acc += ddl;
                 }
                 if (valid && active && q == 0) {
-                    bio<T>::st(r_du, vo, l * sl_du, duv);
-                    bio<T>::st(r_ddt, vo, l * sl_ddt, ddl);
+                    bio<T>::st_cv(r_du, vo, l * sl_du, duv);
+                    bio<T>::st_cv(r_ddt, vo, l * sl_ddt, ddl);
                     if (HAS_Z) {
                         const float dzv = g * ypre * sz * (1.0f + zz[j] * (1.0f - sz));
-                        bio<T>::st(r_dz, vo, zrow[j] * sl_dz, dzv);
+                        bio<T>::st_cv(r_dz, vo, zrow[j] * sl_dz, dzv);
                     }
                 }
                 if constexpr (MFMA_RED) {
