@@ -32,7 +32,7 @@ template <> struct vio<bf16_t, 2> {
     }
     static __device__ __forceinline__ void st(bf16_t* p, const float (&v)[2]) {
         uint32_t w;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(v[0]), "v"(v[1]));
+        w = dm_cvt_pk_bf16(v[0], v[1]);
         *reinterpret_cast<uint32_t*>(p) = w;
     }
 };

@@ -35,7 +35,7 @@ template <> struct xp_mfma<bf16_t> {
     }
     static __device__ __forceinline__ uint32_t pack(float lo, float hi) {
         uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+        r = dm_cvt_pk_bf16(lo, hi);                      // (through the compiler: -3 % K3x, -5 % K4x against the inline-asm form)
         return r;
     }
     static __device__ __forceinline__ void unpack(uint32_t w, float& lo, float& hi) {

@@ -21,19 +21,17 @@ struct f16_t { _Float16 v; };
 
 // fp32 -> bf16 (round-to-nearest-even, NaN-safe) in ONE instruction: gfx950 has v_cvt_pk_bf16_f32 but no clang
 // builtin for it; the software sequence is 7 VALU ops per store.
-__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(r) : "v"(x));
-    return r & 0xffffu;
-}
-
-// The same instruction emitted by the compiler (vector fptrunc), for code whose schedule benefits from the compiler knowing
-// the instruction (K2: -2.5 %) or that converts MFMA results directly (an inline-asm reader of an MFMA result gets no wait
-// states).  K1 measures 5 % SLOWER with it, so both forms exist.
+// v_cvt_pk_bf16_f32 emitted by the compiler (vector fptrunc): the scheduler knows its latency (K2 -2.5 %, K4x -5 %, K3x -3 %
+// against the inline-asm form used before) and inserts the wait states a reader of MFMA results needs (an inline-asm reader
+// gets none).  K1's SRD store and checkpoint pack keep the inline-asm form: that kernel measures 5 % SLOWER with this one.
 typedef __bf16 dm_bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float dm_f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t dm_cvt_pk_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((dm_f32x2_t){lo, hi}, dm_bf16x2_t));
+}
+
+__device__ __forceinline__ uint32_t f32_to_bf16_bits(float x) {
+    return dm_cvt_pk_bf16(x, x) & 0xffffu;
 }
 
 template <typename T> struct io;
