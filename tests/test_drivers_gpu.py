@@ -150,11 +150,12 @@ def _dist_env(monkeypatch, port):
         monkeypatch.setenv(k, v)
 
 
-@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16", "bf16-graph", "bf16-graph-split", "bf16-gradcomp"])
+@pytest.mark.parametrize("mode", ["bf16", "fp32", "fp16", "bf16-graph", "bf16-graph-split", "bf16-gradcomp", "bf16-mamba2"])
 def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
     """train.py:main (reference train.py:90-311) on one GPU through RCCL + DDP: DiffMa-S/2 (196 tokens) on synthetic latents,
     bf16 autocast (default), fp32, the reference's fp16 + GradScaler mode, the graphed step (one graph, and the data-parallel
-    form: two graphs around one RCCL all-reduce of the flattened gradients), and the opt-in bf16 gradient all-reduce.  Checks: step count, the reference-format checkpoint, finite weights that moved, EMA = its recurrence."""
+    form: two graphs around one RCCL all-reduce of the flattened gradients), the opt-in bf16 gradient all-reduce, and
+    --use-mamba2 (the SSD core on the matrix pipe: the step must launch dm_ssd_fwd / dm_ssd_bwd and no scan).  Checks: step count, the reference-format checkpoint, finite weights that moved, EMA = its recurrence."""
     import socket
 
     from diffma_amd import train as train_mod
@@ -168,18 +169,27 @@ def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
     _dist_env(monkeypatch, port)
     if mode == "bf16-graph-split":
         monkeypatch.setenv("DIFFMA_GRAPH_SPLIT", "1")
+    m2 = mode == "bf16-mamba2"
+    calls = {"ssd_fwd": 0, "ssd_bwd": 0, "scan_fwd": 0, "scan_bwd": 0}
+    if m2:
+        from diffma_amd import hip_ops
+        for name in calls:
+            real = getattr(hip_ops, name)
+            monkeypatch.setattr(hip_ops, name, (lambda real, name: lambda *a, **k: (calls.__setitem__(name, calls[name] + 1), real(*a, **k))[1])(real, name))
     cfg = Config(model="DiffMa-S/2", image_size=224, dt_rank=16, d_state=16, global_batch_size=4, global_seed=0, lr=1e-4, lr_=1e-4,
                  epochs=1, accumulation_steps=1, log_every=1, ckpt_every=3, results_dir=str(tmp_path / "res"),
                  init_from_pretrain_ckpt=False, pretrain_ckpt_path="", init_train_steps=0, synthetic=True, synthetic_samples=64,
                  max_steps=3, autocast=mode != "fp32", amp_dtype="fp16" if mode == "fp16" else "bf16",
-                 graph_train=mode.startswith("bf16-graph"), grad_compression="bf16" if mode == "bf16-gradcomp" else "none")
+                 graph_train=mode.startswith("bf16-graph"), grad_compression="bf16" if mode == "bf16-gradcomp" else "none", use_mamba2=m2)
     assert train_mod.main(cfg) == 3
+    if m2:                                                                 # 4 blocks x 2 mixers x 3 steps, nothing on the scan pair
+        assert calls == {"ssd_fwd": 24, "ssd_bwd": 24, "scan_fwd": 0, "scan_bwd": 0}, calls
     ck = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path) for f in fs if f.endswith("0000003.pt")]
     assert len(ck) == 1
     sd = torch.load(ck[0], map_location="cpu", weights_only=False)
     assert set(sd) == {"model", "ema", "opt", "args"}
     torch.manual_seed(0)                                                   # the seed rule of train.py:99 at world 1, rank 0
-    init = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16).state_dict()
+    init = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16, use_mamba2=m2).state_dict()
     k = "final_layer.linear.weight"                                        # zero-initialised: every step moves it by ~lr
     assert all(torch.isfinite(v).all() for v in sd["model"].values())
     moved = (sd["model"][k] - init[k]).abs().max().item()
@@ -187,7 +197,7 @@ def test_train_main_runs_on_gpu(gpu, monkeypatch, tmp_path, mode):
     # EMA after 3 steps from a decay-0 copy of the init: 0.999^3 w0 + sum_i 0.001 * 0.999^(3-i) w_i; bounded by the model's travel
     e = (sd["ema"][k] - init[k]).abs().max().item()
     assert 0 < e < moved * 0.01, (e, moved)
-    net = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16)
+    net = DiffMa_models["DiffMa-S/2"](input_size=28, dt_rank=16, d_state=16, use_mamba2=m2)
     net.load_state_dict(sd["ema"], strict=True)
 
 
