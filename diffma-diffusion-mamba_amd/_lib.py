@@ -26,6 +26,7 @@ DM_FLAG_A_SHARED = 8
 DM_FLAG_SCAN_SEQUENTIAL = 16
 DM_FLAG_SCAN_CHUNKED = 32
 DM_FLAG_OUT_ACCUMULATE = 64
+DM_FLAG_DELTA_ACTIVATED = 128
 
 _SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 
@@ -85,6 +86,8 @@ dm_conv_bwd_args = _make_struct("dm_conv_bwd_args")
 dm_conv_xproj_fwd_args = _make_struct("dm_conv_xproj_fwd_args")
 dm_conv_xproj_bwd_args = _make_struct("dm_conv_xproj_bwd_args")
 dm_merge_args = _make_struct("dm_merge_args")
+dm_gate_bwd_args = _make_struct("dm_gate_bwd_args")
+dm_dtproj_args = _make_struct("dm_dtproj_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
@@ -130,7 +133,7 @@ def load():
                 fn.argtypes = [ctypes.c_int] * 4
             elif name == "dm_scan_bwd_launch_group_channels":
                 fn.argtypes = [ctypes.c_int] * 5
-            elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported"):
+            elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -8,7 +8,32 @@
 
 namespace dm {
 
-template <typename TI, typename TO, int VEC>
+// 16-byte (or narrower) vector move of VEC elements
+template <typename T, int VEC>
+__device__ __forceinline__ void vec_ld(T (&tmp)[VEC], const T* src) {
+    if constexpr (VEC * sizeof(T) == 16) {
+        *(f32x4*)tmp = *(const f32x4*)src;
+    } else if constexpr (VEC * sizeof(T) == 8) {
+        *(f32x2*)tmp = *(const f32x2*)src;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) tmp[j] = src[j];
+    }
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void vec_st(T* dst, const T (&tmp)[VEC]) {
+    if constexpr (VEC * sizeof(T) == 16) {
+        *(f32x4*)dst = *(const f32x4*)tmp;
+    } else if constexpr (VEC * sizeof(T) == 8) {
+        *(f32x2*)dst = *(const f32x2*)tmp;
+    } else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) dst[j] = tmp[j];
+    }
+}
+
+// GATE: out = (sum) * silu(gate row), optional `pre` = the ungated sum (see include/diffma_hip.h)
+template <typename TI, typename TO, int VEC, bool GATE = false>
 __global__ __launch_bounds__(256) void merge_kernel(const dm_merge_args p) {
     // grid.x covers dim/VEC vectors of one row in blocks of 256 threads; grid.y = seqlen; grid.z = batch
     const int v = blockIdx.x * 256 + threadIdx.x;
@@ -33,6 +58,20 @@ __global__ __launch_bounds__(256) void merge_kernel(const dm_merge_args p) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += io<TI>::ld(&tmp[j]);
     }
+    if constexpr (GATE) {
+        alignas(16) TI zv[VEC];
+        vec_ld<TI, VEC>(zv, (const TI*)p.gate + (int64_t)b * p.g_sb + (int64_t)t * p.g_sl + (int64_t)v * VEC);
+        if (p.pre) {
+            alignas(16) TI pv[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) io<TI>::st(&pv[j], acc[j]);
+            vec_st<TI, VEC>((TI*)p.pre + (int64_t)b * p.p_sb + (int64_t)t * p.p_sl + (int64_t)v * VEC, pv);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = io<TI>::ld(&pv[j]);      // gate the ROUNDED sum: the backward differentiates what it reads back
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] *= silu_f(io<TI>::ld(&zv[j]));
+    }
     alignas(16) TO outv[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) io<TO>::st(&outv[j], acc[j]);
@@ -50,15 +89,19 @@ __global__ __launch_bounds__(256) void merge_kernel(const dm_merge_args p) {
 template <typename TI, typename TO>
 static int launch_merge(const dm_merge_args& a, hipStream_t st) {
     constexpr int VECMAX = 16 / sizeof(TI);
-    const bool vec_ok = (a.dim % VECMAX == 0) && (a.in_sk % VECMAX == 0) && (a.in_sb % VECMAX == 0) &&
-                        (a.in_sl % VECMAX == 0) && (a.o_sb % VECMAX == 0) && (a.o_sl % VECMAX == 0) &&
-                        (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.out) % 16 == 0);
+    bool vec_ok = (a.dim % VECMAX == 0) && (a.in_sk % VECMAX == 0) && (a.in_sb % VECMAX == 0) &&
+                  (a.in_sl % VECMAX == 0) && (a.o_sb % VECMAX == 0) && (a.o_sl % VECMAX == 0) &&
+                  (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.out) % 16 == 0);
+    if (a.gate) vec_ok = vec_ok && (a.g_sb % VECMAX == 0) && (a.g_sl % VECMAX == 0) && (((uintptr_t)a.gate) % 16 == 0);
+    if (a.pre) vec_ok = vec_ok && (a.p_sb % VECMAX == 0) && (a.p_sl % VECMAX == 0) && (((uintptr_t)a.pre) % 16 == 0);
     if (vec_ok) {
         dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch);
-        hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX>), grid, dim3(256), 0, st, a);
+        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX>), grid, dim3(256), 0, st, a);
     } else {
         dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch);
-        hipLaunchKernelGGL((merge_kernel<TI, TO, 1>), grid, dim3(256), 0, st, a);
+        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, 1, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((merge_kernel<TI, TO, 1>), grid, dim3(256), 0, st, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_token_merge: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
@@ -74,6 +117,8 @@ extern "C" int dm_token_merge(const dm_merge_args* args, void* stream) {
     if (!a.in || !a.out) { set_error("dm_token_merge: null tensor pointer"); return DM_ERR_ARG; }
     if (a.nin <= 0 || a.batch <= 0 || a.seqlen <= 0 || a.dim <= 0) { set_error("dm_token_merge: non-positive size"); return DM_ERR_ARG; }
     if (a.batch > 65535 || a.seqlen > 65535) { set_error("dm_token_merge: batch/seqlen > 65535"); return DM_ERR_ARG; }
+    if (a.pre && !a.gate) { set_error("dm_token_merge: pre is only written by the gated form (gate != NULL)"); return DM_ERR_ARG; }
+    if (a.gate && a.io_dtype != a.out_dtype) { set_error("dm_token_merge: the gated form keeps one dtype (in, gate, pre, out)"); return DM_ERR_DTYPE; }
     hipStream_t st = (hipStream_t)stream;
     if (a.io_dtype == DM_F32 && a.out_dtype == DM_F32) return launch_merge<float, float>(a, st);
     if (a.io_dtype == DM_BF16 && a.out_dtype == DM_BF16) return launch_merge<bf16_t, bf16_t>(a, st);
@@ -82,6 +127,69 @@ extern "C" int dm_token_merge(const dm_merge_args* args, void* stream) {
     if (a.io_dtype == DM_F32 && a.out_dtype == DM_F16) return launch_merge<float, f16_t>(a, st);
     set_error("dm_token_merge: unsupported dtype pair (%d -> %d)", a.io_dtype, a.out_dtype);
     return DM_ERR_DTYPE;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dm_gate_bwd -- backward of the hoisted gate y = pre * silu(z):  g = dy * silu(z),  dz = dy * pre * silu'(z).
+// One pass over the [batch][seqlen][dim] token-order tensors (3 reads + 2 writes per element, 16-B accesses); replaces
+// sigmoid / silu' / the y re-accumulation / the dz store inside the three per-direction scan backwards and the 3-slab dz merge.
+// ------------------------------------------------------------------------------------------------------------
+namespace dm {
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const dm_gate_bwd_args p) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    const int b = blockIdx.z;
+    if (v * VEC >= p.dim) return;
+    const int64_t c = (int64_t)v * VEC;
+    alignas(16) T dyv[VEC], zv[VEC], pv[VEC], gv[VEC], dzv[VEC];
+    vec_ld<T, VEC>(dyv, (const T*)p.dy + (int64_t)b * p.dy_sb + (int64_t)t * p.dy_sl + c);
+    vec_ld<T, VEC>(zv, (const T*)p.z + (int64_t)b * p.z_sb + (int64_t)t * p.z_sl + c);
+    vec_ld<T, VEC>(pv, (const T*)p.pre + (int64_t)b * p.p_sb + (int64_t)t * p.p_sl + c);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const float dy = io<T>::ld(&dyv[j]), z = io<T>::ld(&zv[j]), pre = io<T>::ld(&pv[j]);
+        const float sg = sigmoid_f(z);
+        io<T>::st(&gv[j], dy * z * sg);
+        io<T>::st(&dzv[j], dy * pre * sg * (1.0f + z * (1.0f - sg)));
+    }
+    vec_st<T, VEC>((T*)p.g + (int64_t)b * p.g_sb + (int64_t)t * p.g_sl + c, gv);
+    vec_st<T, VEC>((T*)p.dz + (int64_t)b * p.dz_sb + (int64_t)t * p.dz_sl + c, dzv);
+}
+
+template <typename T>
+static int launch_gate_bwd(const dm_gate_bwd_args& a, hipStream_t st) {
+    constexpr int VECMAX = 16 / sizeof(T);
+    auto al = [&](const void* ptr, int64_t sb, int64_t sl) { return (uintptr_t)ptr % 16 == 0 && sb % VECMAX == 0 && sl % VECMAX == 0; };
+    const bool vec_ok = a.dim % VECMAX == 0 && al(a.dy, a.dy_sb, a.dy_sl) && al(a.z, a.z_sb, a.z_sl) && al(a.pre, a.p_sb, a.p_sl) &&
+                        al(a.g, a.g_sb, a.g_sl) && al(a.dz, a.dz_sb, a.dz_sl);
+    if (vec_ok) {
+        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch);
+        hipLaunchKernelGGL((gate_bwd_kernel<T, VECMAX>), grid, dim3(256), 0, st, a);
+    } else {
+        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch);
+        hipLaunchKernelGGL((gate_bwd_kernel<T, 1>), grid, dim3(256), 0, st, a);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_gate_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
+}  // namespace dm
+
+extern "C" int dm_gate_bwd(const dm_gate_bwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_gate_bwd: null args"); return DM_ERR_ARG; }
+    const dm_gate_bwd_args& a = *args;
+    if (!a.dy || !a.z || !a.pre || !a.g || !a.dz) { set_error("dm_gate_bwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.batch <= 0 || a.seqlen <= 0 || a.dim <= 0) { set_error("dm_gate_bwd: non-positive size"); return DM_ERR_ARG; }
+    if (a.batch > 65535 || a.seqlen > 65535) { set_error("dm_gate_bwd: batch/seqlen > 65535"); return DM_ERR_ARG; }
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.io_dtype) {
+        case DM_F32: return launch_gate_bwd<float>(a, st);
+        case DM_BF16: return launch_gate_bwd<bf16_t>(a, st);
+        case DM_F16: return launch_gate_bwd<f16_t>(a, st);
+        default: set_error("dm_gate_bwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -31,6 +31,10 @@ extern "C" int dm_selective_scan_bwd(const dm_scan_bwd_args* args, void* stream)
         set_error("dm_selective_scan_bwd: dim/ngroups must be a multiple of 64"); return DM_ERR_LAYOUT;
     }
     if (a.batch_per_dir > 0 && a.nseq % a.batch_per_dir != 0) { set_error("dm_selective_scan_bwd: nseq %% batch_per_dir != 0"); return DM_ERR_ARG; }
+    if ((a.flags & DM_FLAG_DELTA_ACTIVATED) && (a.z || !a.z_row_index || a.dstate != 16 || (a.flags & (DM_FLAG_A_SHARED | DM_FLAG_DELTA_SOFTPLUS)))) {
+        set_error("dm_selective_scan_bwd: DM_FLAG_DELTA_ACTIVATED is built for the mixer's call pattern (no z, row indices, d_state 16, no A_SHARED / DELTA_SOFTPLUS)");
+        return DM_ERR_ARG;
+    }
     if ((a.z_row_index == nullptr) != (a.out_row_index == nullptr)) {
         set_error("dm_selective_scan_bwd: z_row_index and out_row_index must both be set or both be NULL"); return DM_ERR_ARG;
     }

@@ -33,7 +33,7 @@ __device__ __forceinline__ float row_sum16(float x) {
     return x;
 }
 
-template <typename T, typename TBC, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC, bool ASH = false>
+template <typename T, typename TBC, bool HAS_Z, bool IDX, int DMODE, int NW, int LC, bool ASH = false>   // DMODE: scan_bwd_impl.h
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void scan_bwd_chunked_kernel(const dm_scan_bwd_args p) {
     constexpr int N = 16, NPL = N / 2, SUB = BWD_SUB, M = 2 * N, NSUB = LC / SUB;
     constexpr int ES = (int)sizeof(T);
@@ -110,8 +110,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     auto finish_sub = [&](int sc, Sub& in) {                                      // softplus, zero gradients past the end
 #pragma unroll
         for (int i = 0; i < SUB; ++i) {
-            float x = in.dl[i] + bias;
-            if (SOFTPLUS) x = softplus_f(x);
+            float x = in.dl[i];
+            if (DMODE != 2) x += bias;
+            if (DMODE == 1) x = softplus_f(x);
             in.dl[i] = x;
             in.gg[i] = ((l0 + sc * SUB + i) < L && active) ? in.gg[i] : 0.f;
         }
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
             const float dlA = dlA2.x + dlA2.y;
             float ddl = in.uu[i] * GB + LN2 * dlA;
             const float duv = dlo * GB + gy * Dv;
-            if (SOFTPLUS) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));
+            if (DMODE != 0) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));
             dD_acc += gy * in.uu[i];
             dbias_acc += ddl;
             if (valid && active) {
@@ -390,12 +391,18 @@ static void launch_bwd_chunked3(const dm_scan_bwd_args& a, hipStream_t st) {
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
     if constexpr (HAS_Z && IDX) {
         if ((a.flags & DM_FLAG_A_SHARED) && sp) {
-            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, true, true, true, BWD_CHUNKED_NW, LC, true>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, true, true, 1, BWD_CHUNKED_NW, LC, true>), grid, block, 0, st, a);
             return;
         }
     }
-    if (sp) hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, true, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, false, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
+    if constexpr (!HAS_Z && IDX) {                    // hoisted gate + hoisted softplus (the DiffMa mixer's call pattern)
+        if (a.flags & DM_FLAG_DELTA_ACTIVATED) {
+            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, false, true, 2, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
+            return;
+        }
+    }
+    if (sp) hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 1, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 0, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
 }
 
 template <typename T, typename TBC>

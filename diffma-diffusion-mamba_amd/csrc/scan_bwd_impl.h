@@ -128,7 +128,10 @@ __device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
     }
 }
 
-template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, bool SOFTPLUS, bool ASH = false>
+// DMODE (delta mode): 0 = delta + bias used as is, 1 = softplus(delta + bias) (DM_FLAG_DELTA_SOFTPLUS), 2 = delta already holds
+// softplus(raw + bias) (DM_FLAG_DELTA_ACTIVATED: the producer of delta applied it once per element instead of every scan
+// direction twice); the returned ddelta is the gradient of the RAW value in every mode: softplus'(x) = 1 - exp(-softplus(x)).
+template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, int DMODE, bool ASH = false>
 __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 2 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
@@ -324,8 +327,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
             const bool valid = (l0 + j) < L;
-            float x = dl[j] + bias;
-            if (SOFTPLUS) x = softplus_f(x);
+            float x = dl[j];
+            if (DMODE != 2) x += bias;
+            if (DMODE == 1) x = softplus_f(x);
             dl[j] = x;                                    // tail steps re-read row L-1: finite garbage that only meets g = 0
             gg[j] = (valid && active) ? gg[j] : 0.f;
         }
@@ -437,7 +441,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
                 float ddl = uu[j] * GB + LN2 * dlA;
                 const float duv = dlo * GB + gy * Dv;
-                if (SOFTPLUS) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));   // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
+                if (DMODE != 0) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));   // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
                 if (q == 0) {                                             // one lane per channel owns the channel sums
                     dD_acc += gy * uu[j];
                     dbias_acc += ddl;
@@ -494,14 +498,20 @@ template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {
     if constexpr (N == 16 && HAS_Z && IDX) {          // the one-exp variant is built for the Mamba-2 call pattern only
         if ((a.flags & DM_FLAG_A_SHARED) && (a.flags & DM_FLAG_DELTA_SOFTPLUS)) {
-            hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, true, true, true, true>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
+            hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, true, true, 1, true>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
+            return;
+        }
+    }
+    if constexpr (N == 16 && !HAS_Z && IDX) {         // the hoisted-gate / hoisted-softplus call pattern of the DiffMa mixer
+        if (a.flags & DM_FLAG_DELTA_ACTIVATED) {
+            hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, false, true, 2>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
             return;
         }
     }
     if (a.flags & DM_FLAG_DELTA_SOFTPLUS)
-        hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, HAS_Z, IDX, true>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
+        hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, HAS_Z, IDX, 1>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
     else
-        hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, HAS_Z, IDX, false>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
+        hipLaunchKernelGGL((scan_bwd_kernel<T, TBC, N, bwd_split<N>::value, HAS_Z, IDX, 0>), grid, dim3(WAVE * BWD_WAVES), 0, st, a);
 }
 
 template <typename T, typename TBC, int N>

@@ -11,7 +11,11 @@ int scan_fwd_f16(const dm_scan_fwd_args& a, hipStream_t st);
 extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream) {
     using namespace dm;
     if (!args) { set_error("dm_selective_scan_fwd: null args"); return DM_ERR_ARG; }
-    const dm_scan_fwd_args& a = *args;
+    dm_scan_fwd_args a = *args;
+    if (a.flags & DM_FLAG_DELTA_ACTIVATED) {          // delta already holds softplus(raw + bias): the forward uses it as is
+        a.flags &= ~(DM_FLAG_DELTA_ACTIVATED | DM_FLAG_DELTA_SOFTPLUS);
+        a.delta_bias = nullptr;
+    }
     if (!a.u || !a.delta || !a.out || !a.A || !a.B || !a.C) {
         set_error("dm_selective_scan_fwd: null tensor pointer"); return DM_ERR_ARG;
     }

@@ -174,7 +174,8 @@ static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
     const int forced = (a.flags & DM_FLAG_SCAN_SEQUENTIAL) ? 0 : ((a.flags & DM_FLAG_SCAN_CHUNKED) ? 1 : env);
     if (forced == 0 || (a.flags & DM_FLAG_OUT_ACCUMULATE)) return false;
     const int64_t waves = (int64_t)a.nseq * ((a.dim + WAVE - 1) / WAVE);
-    if (a.ckpt && !(a.z && a.z_row_index && (a.flags & DM_FLAG_DELTA_SOFTPLUS))) return false;   // checkpoints: model call pattern only
+    // checkpoints: built for the two model call patterns only (gated + softplus in the scan; gate and softplus hoisted out of it)
+    if (a.ckpt && !(a.z_row_index && ((a.z && (a.flags & DM_FLAG_DELTA_SOFTPLUS)) || (!a.z && !(a.flags & DM_FLAG_DELTA_SOFTPLUS))))) return false;
     return !a.last_state && a.dstate == 16 && (waves <= 512 || forced == 1) && a.seqlen > 4 * CHUNKED_NW &&
            a.seqlen <= CHUNKED_NW * CHUNKED_LC;
 }
@@ -191,6 +192,12 @@ static void launch_fwd_chunked2(const dm_scan_fwd_args& a, hipStream_t st) {
         }
         if (a.ckpt && sp) {
             hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, a);
+            return;
+        }
+    }
+    if constexpr (!HAS_Z && IDX) {                  // hoisted gate + hoisted softplus (DM_FLAG_DELTA_ACTIVATED arrives here as "no softplus, no bias")
+        if (a.ckpt && !sp) {
+            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, false, true, false, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, a);
             return;
         }
     }

@@ -11,8 +11,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_scan_bwd_args, dm_scan_fwd_args)
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -158,11 +158,13 @@ def _variant_flag(variant):
 
 def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, out=None, ckpt=None,
-             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False, variant=None, acc_dirs=False):
+             ckpt_every=SCAN_CKPT_EVERY, last_state=None, ngroups=1, a_shared=False, variant=None, acc_dirs=False,
+             delta_activated=False):
     """u, delta: [S, L, Dm] token-major (last stride 1).  Bm, Cm: [S, L, G*N] views (state stride 1).
     z: [S or S/ndir, Lz, Dm] or None.  A: [Dm, N] fp32.  Returns out [S, L, Dm] (allocated if None).
     acc_dirs: the ndir directions are accumulated into ONE token-order buffer [batch_per_dir, L, Dm], which is returned: one
-    launch per direction, the first stores, the others add (DM_FLAG_OUT_ACCUMULATE) -- CrossMerge folded into the scan."""
+    launch per direction, the first stores, the others add (DM_FLAG_OUT_ACCUMULATE) -- CrossMerge folded into the scan.
+    delta_activated: delta already holds softplus(raw + bias) (dtproj_softplus); delta_bias / delta_softplus are then ignored."""
     _require_gpu(u, delta, A, Bm, Cm, z)
     S, L, Dm = u.shape
     N = A.shape[1]
@@ -180,11 +182,11 @@ def scan_fwd(u, delta, A, Bm, Cm, D=None, z=None, delta_bias=None, delta_softplu
     if out is None:
         out = torch.empty((S, L, Dm), dtype=u.dtype, device=u.device)
     return _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_row_index, out_row_index, batch_per_dir, out, ckpt,
-                            ckpt_every, last_state, ngroups, a_shared, variant, False)
+                            ckpt_every, last_state, ngroups, a_shared, variant, False, delta_activated)
 
 
 def _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_row_index, out_row_index, batch_per_dir, out, ckpt,
-                     ckpt_every, last_state, ngroups, a_shared, variant, accumulate):
+                     ckpt_every, last_state, ngroups, a_shared, variant, accumulate, delta_activated=False):
     S, L, Dm = u.shape
     N = A.shape[1]
     A = _f32c(A)
@@ -198,6 +200,8 @@ def _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_ro
     a.bc_dtype = dtype_code(Bm)
     a.flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_A_SHARED if a_shared else 0) | _variant_flag(variant)
                | (DM_FLAG_OUT_ACCUMULATE if accumulate else 0))
+    if delta_activated:
+        a.flags = (a.flags & ~DM_FLAG_DELTA_SOFTPLUS) | DM_FLAG_DELTA_ACTIVATED
     a.ckpt_every = ckpt_every
     a.ckpt_dtype = _ckpt_dtype_code(ckpt)
     a.u, a.delta, a.z, a.out = _ptr(u), _ptr(delta), _ptr(z), _ptr(out)
@@ -224,15 +228,19 @@ def _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_ro
 
 def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=True, *,
              z_row_index=None, out_row_index=None, batch_per_dir=0, ckpt_every=SCAN_CKPT_EVERY,
-             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False, dbc_out=None, variant=None):
+             ngroups=1, dz_out=None, dout_per_seq=False, du_out=None, a_shared=False, dbc_out=None, variant=None,
+             delta_activated=False):
     """Reverse-time pass.  Returns (du, ddelta, dz, dB, dC, dA, dD, dbias) with parameter gradients
     already reduced over sequences.  dz is [S, Lz, Dm] in the z buffer's row order (token order when
-    z_row_index is given)."""
+    z_row_index is given).  delta_activated: delta holds softplus(raw + bias) already (DM_FLAG_DELTA_ACTIVATED); ddelta and dbias
+    are still the gradients of the raw value / of the bias."""
     _require_gpu(u, delta, A, Bm, Cm, z, dout, ckpt)
     S, L, Dm = u.shape
     N = A.shape[1]
     flags = ((DM_FLAG_DELTA_SOFTPLUS if delta_softplus else 0) | (DM_FLAG_DOUT_PER_SEQ if dout_per_seq else 0)
              | (DM_FLAG_A_SHARED if a_shared else 0) | _variant_flag(variant))
+    if delta_activated:
+        flags = (flags & ~DM_FLAG_DELTA_SOFTPLUS) | DM_FLAG_DELTA_ACTIVATED
     gc = _lib.load().dm_scan_bwd_launch_group_channels(S, Dm, L, N, flags)   # 256 (sequential kernel) or 64 (chunk-parallel, small launches)
     if gc <= 0:
         raise _lib.DiffmaHipError(f"selective-scan backward is not built for d_state={N}")
@@ -247,7 +255,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     dBC = torch.empty((S, L, nw, 2 * N), dtype=torch.float32, device=dev)
     dA = torch.empty((S, Dm, N), dtype=torch.float32, device=dev)
     dD = torch.empty((S, Dm), dtype=torch.float32, device=dev) if D is not None else None
-    dbias = torch.empty((S, Dm), dtype=torch.float32, device=dev) if delta_bias is not None else None
+    dbias = torch.empty((S, Dm), dtype=torch.float32, device=dev) if (delta_bias is not None or delta_activated) else None
     a = dm_scan_bwd_args()
     a.nseq, a.dim, a.seqlen, a.dstate = S, Dm, L, N
     a.ngroups = ngroups
@@ -475,14 +483,24 @@ def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=Tru
     return dx, colsum(dw.view(ndir * Bsz * nchunk, Dm * W), True).view(Dm, W), colsum(db.view(ndir * Bsz * nchunk, Dm), True)
 
 
-def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
-    """slabs: [K, B, L, Dm] (last stride 1) -> out [B, L, Dm] = sum_k slabs[k][:, idx_k, :]."""
-    _require_gpu(slabs)
+def token_merge(slabs, *, row_index=None, out=None, out_dtype=None, gate=None, pre_out=None):
+    """slabs: [K, B, L, Dm] (last stride 1) -> out [B, L, Dm] = sum_k slabs[k][:, idx_k, :].
+    gate [B, L, Dm] view: out = sum * silu(gate) (the SiLU(z) gate of the K per-direction operators applied once per token);
+    pre_out [B, L, Dm]: receives the ungated sum (saved for gate_bwd)."""
+    _require_gpu(slabs, gate)
     K, Bsz, L, Dm = slabs.shape
     if out is None:
         out = torch.empty((Bsz, L, Dm), dtype=out_dtype or slabs.dtype, device=slabs.device)
     assert slabs.stride(3) == 1 and out.stride(2) == 1
     a = dm_merge_args()
+    if gate is not None:
+        assert gate.shape == (Bsz, L, Dm) and gate.stride(2) == 1 and gate.dtype == slabs.dtype and out.dtype == slabs.dtype
+        a.gate = _ptr(gate)
+        a.g_sb, a.g_sl = gate.stride()[:2]
+        if pre_out is not None:
+            assert pre_out.shape == (Bsz, L, Dm) and pre_out.stride(2) == 1 and pre_out.dtype == slabs.dtype
+            a.pre = _ptr(pre_out)
+            a.p_sb, a.p_sl = pre_out.stride()[:2]
     a.nin, a.batch, a.seqlen, a.dim = K, Bsz, L, Dm
     a.io_dtype, a.out_dtype = dtype_code(slabs), dtype_code(out)
     a.row_index = _ptr(row_index)
@@ -490,8 +508,63 @@ def token_merge(slabs, *, row_index=None, out=None, out_dtype=None):
     setattr(a, "in", _ptr(slabs))
     a.in_sk, a.in_sb, a.in_sl = slabs.stride()[:3]
     a.o_sb, a.o_sl = out.stride()[:2]
-    _launch("dm_token_merge", a, slabs, (K * slabs.element_size() + out.element_size()) * Bsz * L * Dm)
+    extra = (0 if gate is None else 1) + (0 if pre_out is None else 1)
+    _launch("dm_token_merge", a, slabs, ((K + extra) * slabs.element_size() + out.element_size()) * Bsz * L * Dm)
     return out
+
+
+def gate_bwd(dy, z, pre, *, dz_out=None):
+    """Backward of y = pre * silu(z) (token_merge(..., gate=z)): returns (g = dy * silu(z), dz = dy * pre * silu'(z)).
+    dy, pre: [B, L, Dm]; z: [B, L, Dm] view; dz_out: optional [B, L, Dm] view (e.g. the z half of d(xz))."""
+    _require_gpu(dy, z, pre)
+    Bsz, L, Dm = dy.shape
+    assert z.shape == dy.shape and pre.shape == dy.shape and z.dtype == dy.dtype and pre.dtype == dy.dtype
+    assert dy.stride(2) == 1 and z.stride(2) == 1 and pre.stride(2) == 1
+    g = torch.empty((Bsz, L, Dm), dtype=dy.dtype, device=dy.device)
+    dz = dz_out if dz_out is not None else torch.empty((Bsz, L, Dm), dtype=dy.dtype, device=dy.device)
+    assert dz.stride(2) == 1 and dz.dtype == dy.dtype
+    a = dm_gate_bwd_args()
+    a.batch, a.seqlen, a.dim = Bsz, L, Dm
+    a.io_dtype = dtype_code(dy)
+    a.dy, a.z, a.pre, a.g, a.dz = _ptr(dy), _ptr(z), _ptr(pre), _ptr(g), _ptr(dz)
+    a.dy_sb, a.dy_sl = dy.stride()[:2]
+    a.z_sb, a.z_sl = z.stride()[:2]
+    a.p_sb, a.p_sl = pre.stride()[:2]
+    a.g_sb, a.g_sl = g.stride()[:2]
+    a.dz_sb, a.dz_sl = dz.stride()[:2]
+    _launch("dm_gate_bwd", a, dy, 5 * Bsz * L * Dm * dy.element_size())
+    return g, dz
+
+
+# dt_proj with softplus in the epilogue (csrc/dtproj.hip); DIFFMA_DTPROJ_FUSED=0 returns the mixer to F.linear + softplus in the scans
+DTPROJ_FUSED = os.environ.get("DIFFMA_DTPROJ_FUSED", "1") == "1"
+
+
+def dtproj_softplus_supported(xdbl, w):
+    if not (DTPROJ_FUSED and xdbl.is_cuda and xdbl.dtype in (torch.bfloat16, torch.float16) and w.dtype == xdbl.dtype):
+        return False
+    if xdbl.stride(-1) != 1 or xdbl.stride(0) % 8 or xdbl.data_ptr() % 16:
+        return False
+    return bool(_lib.load().dm_dtproj_softplus_supported(int(w.shape[0]), int(w.shape[1]), dtype_code(xdbl)))
+
+
+def dtproj_softplus_fwd(xdbl, w, bias):
+    """xdbl: [M, >= R] (row stride a multiple of 8, 16-bit), w: [Dm, R] (dt_proj.weight, same dtype), bias [Dm] fp32 or None.
+    Returns delta [M, Dm] = softplus(xdbl[:, :R] @ w^T + bias) in the I/O dtype."""
+    _require_gpu(xdbl, w, bias)
+    M = xdbl.shape[0]
+    Dm, R = w.shape
+    w = w.contiguous()
+    bias = _f32c(bias)
+    delta = torch.empty((M, Dm), dtype=xdbl.dtype, device=xdbl.device)
+    a = dm_dtproj_args()
+    a.rows, a.dim, a.rank = M, Dm, R
+    a.io_dtype = dtype_code(xdbl)
+    a.xdbl, a.w, a.bias, a.delta = _ptr(xdbl), _ptr(w), _ptr(bias), _ptr(delta)
+    a.xd_sr = xdbl.stride(0)
+    es = xdbl.element_size()
+    _launch("dm_dtproj_softplus_fwd", a, xdbl, M * (Dm + R) * es + Dm * R * es + 4 * Dm)
+    return delta
 
 
 LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK

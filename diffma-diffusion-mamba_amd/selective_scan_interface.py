@@ -14,6 +14,8 @@ inverse reindex folded into row addressing, then the 3-way merge BEFORE out_proj
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -217,6 +219,10 @@ def linear_splitk(x, weight, bias=None):
 # ------------------------------------------------------------------------------------------------
 # Fused 3-direction operator of the DiffMa mixer
 # ------------------------------------------------------------------------------------------------
+# DIFFMA_HOIST_GATE=0: gate (and softplus) back inside every per-direction scan, as upstream evaluates them (A/B runs, tests)
+HOIST_GATE = os.environ.get("DIFFMA_HOIST_GATE", "1") == "1"
+
+
 class _SpiralSSMFn(torch.autograd.Function):
     """xz [B, L, 2*Din] token-major -> merged pre-projection output y [B, L, Din].
 
@@ -246,18 +252,36 @@ class _SpiralSSMFn(torch.autograd.Function):
         else:
             xc = hip_ops.gather_conv1d_fwd(x_view, conv_w, conv_b, row_index=scan_index, ndir=ndir, silu=True)   # [ndir*B, L, Din]
             x_dbl = GemmChain.run(F.linear, xc.view(-1, Din), Wx_c)            # [ndir*B*L, R+2N]
-        delta = GemmChain.run(F.linear, x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
+        # Hoisted gate: CrossScan permutes x and z together and CrossMerge applies the inverse permutation (block/mamba.py:41-45,
+        # 66-68), so merged[t] = silu(z[t]) * sum_k y~_k[t]: the scans run WITHOUT z and the gate is applied once per token by the
+        # merge (one z read in an HBM-bound kernel) instead of three times inside the VALU-bound scans.  Needs the scatter table
+        # to be the gather table (not ViM's) and a merge to ride on.
+        hoist = HOIST_GATE and merge and out_index is None and ndir > 1
+        # Hoisted softplus: delta = softplus(dt_proj(.) + bias) leaves the dt_proj kernel activated (csrc/dtproj.hip) and the scans
+        # run with DM_FLAG_DELTA_ACTIVATED (forward: nothing to evaluate; backward: only 1 - exp(-delta)).
+        act = hoist and hip_ops.dtproj_softplus_supported(x_dbl, Wdt_c)
+        if act:
+            delta = hip_ops.dtproj_softplus_fwd(x_dbl, Wdt_c, dt_bias).view(ndir * Bsz, L, Din)
+        else:
+            delta = GemmChain.run(F.linear, x_dbl[:, :R], Wdt_c).view(ndir * Bsz, L, Din)
         xd3 = x_dbl.view(ndir * Bsz, L, R + 2 * N)
         Bm, Cm = xd3[..., R:R + N], xd3[..., R + N:]
         ckpt = None
         if need_grad:
             ckpt = hip_ops.alloc_scan_ckpt(ndir * Bsz, L, N, Din, xz.dtype, xz.device)
         oidx = scan_index if out_index is None else out_index
+        ctx.merge, ctx.hoist, ctx.act = merge, hoist, act
+        if hoist:
+            ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, None, dt_bias, True, z_row_index=scan_index, out_row_index=oidx,
+                                    batch_per_dir=Bsz, ckpt=ckpt, delta_activated=act)          # token order, NOT gated
+            pre = torch.empty((Bsz, L, Din), dtype=dt_, device=xz.device) if need_grad else None   # ungated sum, kept for dz
+            y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din), gate=z_view, pre_out=pre)
+            ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx, pre)
+            return y
         acc = merge and hip_ops.scan_acc_dirs_ok(xc, ndir, N)      # the 3-way CrossMerge sum done by the scan itself
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
                                 out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt, acc_dirs=acc)     # token order
-        ctx.merge = merge
-        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx)
+        ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx, None)
         if acc:
             return ydir                                            # [B, L, Din], already merged
         if not merge:
@@ -266,7 +290,7 @@ class _SpiralSSMFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx = ctx.saved_tensors
+        xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx, pre = ctx.saved_tensors
         Bsz, L, D2 = xz.shape
         Din = D2 // 2
         ndir = scan_index.shape[0]
@@ -283,10 +307,19 @@ class _SpiralSSMFn(torch.autograd.Function):
         z_view = xz[..., Din:]
         M = ndir * Bsz * L
         dx_dbl = torch.empty((M, R + 2 * N), dtype=dt_, device=xz.device)
-        du, ddelta, dz, _, _, dA, dD, dbias = hip_ops.scan_bwd(
-            xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
-            out_row_index=oidx, batch_per_dir=Bsz, dout_per_seq=not ctx.merge,
-            dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
+        dxz = torch.empty_like(xz)
+        if ctx.hoist:
+            # the gate's backward once per token: g = dy * silu(z) is what the three directions read as their output gradient,
+            # dz = dy * pre * silu'(z) goes straight into the z half of d(xz) (no dz slabs, no 3-slab merge)
+            g, dz = hip_ops.gate_bwd(dy, z_view, pre, dz_out=dxz[..., Din:])
+            du, ddelta, _, _, _, dA, dD, dbias = hip_ops.scan_bwd(
+                xc, delta, A, Bm, Cm, Dskip, None, dt_bias, g, ckpt, True, z_row_index=scan_index, out_row_index=oidx,
+                batch_per_dir=Bsz, dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:], delta_activated=ctx.act)
+        else:
+            du, ddelta, dz, _, _, dA, dD, dbias = hip_ops.scan_bwd(
+                xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, dy, ckpt, True, z_row_index=scan_index,
+                out_row_index=oidx, batch_per_dir=Bsz, dout_per_seq=not ctx.merge,
+                dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
         dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
@@ -300,9 +333,9 @@ class _SpiralSSMFn(torch.autograd.Function):
             dxc = GemmChain.run(du.view(M, Din).addmm_, dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
             dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                    row_index=scan_index, ndir=ndir, silu=True)
-        dxz = torch.empty_like(xz)
         hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
-        hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
+        if not ctx.hoist:
+            hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
         return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
                 dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None, None, None, None)
 

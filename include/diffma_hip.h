@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 17
+#define DM_ABI_VERSION 18
 
 typedef enum {
     DM_OK = 0,
@@ -55,12 +55,19 @@ enum {
     DM_FLAG_SCAN_SEQUENTIAL = 16, /* scan fwd / bwd: take the sequential-in-time kernel whatever the launch size          */
     DM_FLAG_SCAN_CHUNKED = 32,  /* scan fwd / bwd: take the chunk-parallel (two-pass) kernel where it is instantiated;
                                    by default the library chooses by launch size (small launches are latency-bound)       */
-    DM_FLAG_OUT_ACCUMULATE = 64 /* scan fwd with row indices: out[s][out_row_index[l]] += y (read-add-store) instead of = y.
+    DM_FLAG_OUT_ACCUMULATE = 64, /* scan fwd with row indices: out[s][out_row_index[l]] += y (read-add-store) instead of = y.
                                    The caller walks the directions of the CrossMerge (block/mamba.py:59-69) with one launch
                                    each into ONE token-order buffer: direction 0 stores, the others accumulate, and the
                                    separate merge pass disappears.  One direction per launch (batch_per_dir = 0 or nseq),
                                    d_state 16, z, both index tables, DM_FLAG_DELTA_SOFTPLUS, no DM_FLAG_A_SHARED; the
                                    sequential kernel is taken whatever the launch size.                                   */
+    DM_FLAG_DELTA_ACTIVATED = 128 /* scan fwd / bwd: `delta` already holds softplus(raw + delta_bias) -- the producer applied it
+                                   once per element (dm_dtproj_softplus_fwd) instead of every scan direction evaluating it in
+                                   the forward AND in the backward.  Forward: delta is used as is, delta_bias is ignored.
+                                   Backward: ddelta is still the gradient of the RAW value, d raw = d delta * (1 - exp(-delta)),
+                                   and dbias_partial its per-sequence sums.  Built for the DiffMa mixer's call pattern: no z
+                                   (the SiLU gate is applied once per token where the directions meet, dm_token_merge /
+                                   dm_gate_bwd), both row-index tables, d_state 16.                                         */
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -276,6 +283,11 @@ int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype);
  * (out_proj is linear and bias-free, block/mamba.py:240,315, so sum-then-project == project-then-sum
  * up to rounding) and serves as the 3-slab gradient sum of the backward pass.
  * ---------------------------------------------------------------------------------------------- */
+/* Gated form (gate != NULL):  pre[b][t][c] = sum_k in[k][b][idx[k][t]][c] ;  out = pre * silu(gate[b][t][c]).
+ * CrossScan permutes x and z together and CrossMerge applies the inverse permutation (block/mamba.py:41-45,66-68), so the
+ * SiLU(z) gate of the three per-direction operators (mamba_inner_fn, block/mamba.py:346-348) factors out of the 3-way sum:
+ * it is applied ONCE per token here instead of three times inside the scans.  `pre` (optional, io_dtype) keeps the
+ * ungated sum for the backward (dm_gate_bwd). */
 typedef struct {
     int32_t nin, batch, seqlen, dim;
     int32_t io_dtype, out_dtype;
@@ -284,9 +296,52 @@ typedef struct {
     void *out;
     int64_t in_sk, in_sb, in_sl;   /* channel stride 1 */
     int64_t o_sb, o_sl;
+    const void *gate;          /* [batch][seqlen][dim] via strides (io_dtype), or NULL */
+    void *pre;                 /* [batch][seqlen][dim] via strides (io_dtype), or NULL; only with gate */
+    int64_t g_sb, g_sl;
+    int64_t p_sb, p_sl;
 } dm_merge_args;
 
 int dm_token_merge(const dm_merge_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Backward of the hoisted gate  y = pre * silu(z):   g = dy * silu(z)   (what the per-direction scan backwards read as dout)
+ *                                                    dz = dy * pre * silu'(z)      -- once per token, one pass.
+ * All tensors [batch][seqlen][dim] via (batch, row) strides, channel stride 1, one dtype.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, seqlen, dim;
+    int32_t io_dtype;
+    const void *dy, *z, *pre;
+    void *g, *dz;
+    int64_t dy_sb, dy_sl;
+    int64_t z_sb, z_sl;
+    int64_t p_sb, p_sl;
+    int64_t g_sb, g_sl;
+    int64_t dz_sb, dz_sl;
+} dm_gate_bwd_args;
+
+int dm_gate_bwd(const dm_gate_bwd_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * dt_proj with the softplus folded into its epilogue (the dt_proj + softplus stage of mamba_inner_fn, SURVEY.md A.1 step 3-4;
+ * dt_proj.weight [dim][rank], dt_proj.bias [dim], block/mamba.py:262-287):
+ *     delta[m][d] = softplus( sum_r xdbl[m][r] * w[d][r] + bias[d] )          m < rows, r < rank
+ * One v_mfma_f32_16x16x32 per 16 x 16 output tile (rank <= 32; two for rank <= 64); the kernel is bound by the write of
+ * delta.  The scans then run with DM_FLAG_DELTA_ACTIVATED.  16-bit I/O only (xdbl, w, delta share io_dtype; bias fp32).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t rows, dim, rank;
+    int32_t io_dtype;
+    const void *xdbl;          /* [rows][>= rank] , row stride xd_sr elements (a multiple of 8), 16-byte aligned */
+    const void *w;             /* [dim][rank] contiguous */
+    const float *bias;         /* [dim] fp32 or NULL */
+    void *delta;               /* [rows][dim] contiguous */
+    int64_t xd_sr;
+} dm_dtproj_args;
+
+int dm_dtproj_softplus_fwd(const dm_dtproj_args *args, void *stream);
+int dm_dtproj_softplus_supported(int dim, int rank, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * Block elementwise ops of Spiral_MambaBlock.forward (reference block/mamba_block.py:100-115), each one

@@ -787,3 +787,166 @@ def test_ssd_matrix_pipe_agrees_with_the_scan_pair_at_full_size(gpu):
     agree(dad1[0], dA2.float().view(H, P * N).sum(-1), "dA")
     agree(dad1[1], dD2.float().view(H, P).sum(-1), "dD")
     agree(dad1[2], dbias2.float().view(H, P).sum(-1), "d dt_bias")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 3: the SiLU(z) gate and the softplus hoisted out of the per-direction scans (block/mamba.py:41-45,66-68,346-348)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,K", [(2, 49, 128, 3), (1, 7, 200, 2), (2, 196, 1024, 3)])
+def test_token_merge_gated(gpu, dtype, Bsz, L, Dm, K):
+    """out = silu(z) * sum_k slab_k with z read from the strided z half of an xz buffer; `pre` = the ungated sum in the I/O dtype,
+    and the gate is applied to the ROUNDED sum (what the backward reads back)."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(L + Dm)
+    slabs = torch.randn(K, Bsz, L, Dm, generator=g).to(dtype)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g).to(dtype)
+    xz_d = xz.to(gpu)
+    pre = torch.empty(Bsz, L, Dm, dtype=dtype, device=gpu)
+    out = hip_ops.token_merge(slabs.to(gpu), gate=xz_d[..., Dm:], pre_out=pre)
+    s = slabs.float()
+    acc = s[0]
+    for k in range(1, K):
+        acc = acc + s[k]
+    pre_ref = acc.to(dtype)
+    assert torch.equal(pre.cpu(), pre_ref)                                    # same summation order, one rounding
+    z = xz[..., Dm:].double()
+    ref = pre_ref.double() * z * torch.sigmoid(z)
+    rtol, atol = {torch.float32: (2e-6, 1e-6), torch.bfloat16: (1e-2, 1e-3), torch.float16: (2e-3, 1e-4)}[dtype]
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=rtol, atol=atol)
+    out2 = hip_ops.token_merge(slabs.to(gpu), gate=xz_d[..., Dm:])           # without pre: the fp32 sum is gated
+    ref2 = acc.double() * z * torch.sigmoid(z)
+    torch.testing.assert_close(out2.cpu().double(), ref2, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm", [(2, 49, 128), (1, 7, 200), (2, 196, 1024)])
+def test_gate_bwd_matches_autograd(gpu, dtype, Bsz, L, Dm):
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(3 * L + Dm)
+    dy = torch.randn(Bsz, L, Dm, generator=g).to(dtype)
+    pre = torch.randn(Bsz, L, Dm, generator=g).to(dtype)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g).to(dtype)
+    dxz = torch.zeros(Bsz, L, 2 * Dm, dtype=dtype, device=gpu)
+    gd, dz = hip_ops.gate_bwd(dy.to(gpu), xz.to(gpu)[..., Dm:], pre.to(gpu), dz_out=dxz[..., Dm:])
+    z = xz[..., Dm:].double().clone().requires_grad_(True)
+    p = pre.double().clone().requires_grad_(True)
+    (p * torch.nn.functional.silu(z) * dy.double()).sum().backward()
+    rtol, atol = {torch.float32: (1e-5, 1e-6), torch.bfloat16: (1e-2, 2e-3), torch.float16: (2e-3, 2e-4)}[dtype]
+    torch.testing.assert_close(gd.cpu().double(), p.grad, rtol=rtol, atol=atol)
+    torch.testing.assert_close(dxz[..., Dm:].cpu().double(), z.grad, rtol=rtol, atol=atol)
+    assert dz.data_ptr() == dxz[..., Dm:].data_ptr() and float(dxz[..., :Dm].abs().max()) == 0.0   # only the z half is written
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Dm,R,P", [(2 * 196 * 3, 1024, 32, 64), (70, 208, 16, 48), (33, 64, 8, 40), (16 * 9 + 5, 1536, 24, 56)])
+def test_dtproj_softplus_matches_torch(gpu, dtype, M, Dm, R, P):
+    """delta = softplus(x_dbl[:, :R] @ W^T + bias) from the rank-R MFMA kernel (ragged row counts, widths that are not a multiple of
+    the 512-column workgroup, ranks below the MFMA K) against fp64; extreme pre-activations cover the three softplus branches."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(M + Dm + R)
+    xdbl = torch.randn(M, P, generator=g).to(dtype)
+    w = (torch.randn(Dm, R, generator=g) * R ** -0.5).to(dtype)
+    bias = torch.randn(Dm, generator=g)
+    bias[:4] = torch.tensor([30.0, -30.0, -12.0, 19.0])
+    xd, wd = xdbl.to(gpu), w.to(gpu)
+    assert hip_ops.dtproj_softplus_supported(xd, wd)
+    delta = hip_ops.dtproj_softplus_fwd(xd, wd, bias.to(gpu))
+    ref = torch.nn.functional.softplus(xdbl[:, :R].double() @ w.double().t() + bias.double(), threshold=20.0)
+    rtol, atol = {torch.bfloat16: (1e-2, 1e-6), torch.float16: (2e-3, 1e-6)}[dtype]
+    torch.testing.assert_close(delta.cpu().double(), ref, rtol=rtol, atol=atol)
+
+
+def _hoisted_scan_case(gpu, dtype, Bsz, L, Dm, ndir, variant, seed):
+    """The DiffMa mixer's call pattern after the hoists: no z, row-index tables, delta already activated (DM_FLAG_DELTA_ACTIVATED),
+    the pre-gated gradient shared by the directions.  Forward and backward against fp64 autograd of the oracle run on the SAME
+    activated delta; ddelta / dbias must be the gradients of the RAW pre-activation, i.e. times 1 - exp(-delta)."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import selective_scan_ref
+
+    N, S = 16, ndir * Bsz
+    host, d = _inputs(S, L, Dm, N, dtype, seed=seed, dev=gpu, with_z=False)
+    g = torch.Generator().manual_seed(seed + 1)
+    act = torch.nn.functional.softplus(host["delta"].float() + host["bias"]).to(dtype)      # what dm_dtproj_softplus_fwd would hand over
+    perm = torch.stack([torch.randperm(L, generator=g) for _ in range(ndir)]).int()
+    dout = torch.randn(Bsz, L, Dm, generator=g).to(dtype)
+    ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dtype, gpu).zero_()
+    kw = dict(z_row_index=perm.to(gpu), out_row_index=perm.to(gpu), batch_per_dir=Bsz, variant=variant, delta_activated=True)
+    fwd_variant = variant if (variant != "chunked" or 16 * 14 // 4 < L <= 196) else "sequential"
+    out = hip_ops.scan_fwd(d["u"], act.to(gpu), d["A"], d["B"], d["C"], d["D"], None, d["bias"], True, ckpt=ckpt,
+                           **{**kw, "variant": fwd_variant})
+    res = hip_ops.scan_bwd(d["u"], act.to(gpu), d["A"], d["B"], d["C"], d["D"], None, d["bias"], dout.to(gpu), ckpt, True, **kw)
+    torch.cuda.synchronize()
+    du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
+    assert dz is None
+
+    leaf = lambda t: t.float().double().clone().requires_grad_(True)
+    u, dl, A, Bm, Cm, Dp = leaf(host["u"]), leaf(act), leaf(host["A"]), leaf(host["B"]), leaf(host["C"]), leaf(host["D"])
+    cm = lambda t: t.permute(0, 2, 1)
+    y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=None, delta_bias=None, delta_softplus=False))
+    merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+    for k in range(ndir):
+        merged = merged.index_add(1, perm[k].long(), y[k * Bsz:(k + 1) * Bsz])
+    (merged * dout.float().double()).sum().backward()
+    rf, af = TOL[dtype]
+    yref = y.detach()
+    for k in range(ndir):
+        got = out.float().cpu().double()[k * Bsz:(k + 1) * Bsz][:, perm[k].long()]
+        torch.testing.assert_close(got, yref[k * Bsz:(k + 1) * Bsz], rtol=rf, atol=af * max(1.0, yref.abs().max().item()))
+    rtol, atol = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (4e-2, 6e-2), torch.float16: (5e-3, 8e-3)}[dtype]
+
+    def chk(got, ref, name, sum_scale=1.0):
+        sc = max(1.0, ref.abs().max().item())
+        torch.testing.assert_close(got, ref, rtol=rtol, atol=atol * sc * sum_scale, msg=lambda m: f"{name}: {m}")
+
+    draw = dl.grad * (1.0 - torch.exp(-dl.detach()))                                       # chain through softplus: sigmoid(raw)
+    wide = max(1.0, (Dm / 128.0) ** 0.5) if dtype != torch.float32 else 1.0
+    chk(du, u.grad, "du")
+    chk(ddelta, draw, "ddelta (raw)")
+    chk(dB, Bm.grad, "dB", 4.0 * wide)
+    chk(dC, Cm.grad, "dC", 4.0 * wide)
+    chk(dA, A.grad, "dA", 4.0)
+    chk(dD, Dp.grad, "dD", 4.0)
+    chk(dbias, draw.sum((0, 1)), "dbias", 4.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,ndir,variant", [(2, 196, 1024, 3, "sequential"), (2, 49, 128, 3, "sequential"), (1, 13, 200, 2, "sequential"),
+                                                   (2, 196, 128, 3, "chunked"), (1, 100, 200, 3, "chunked"), (2, 49, 128, 3, "chunked")])
+def test_scan_hoisted_call_pattern_matches_oracle_autograd(gpu, dtype, Bsz, L, Dm, ndir, variant):
+    _hoisted_scan_case(gpu, dtype, Bsz, L, Dm, ndir, variant, seed=7 * L + Dm)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spiral_ssm_hoisted_equals_in_scan_gate(gpu, dtype, monkeypatch):
+    """The fused 3-direction mixer core with the gate / softplus hoisted (default) against the same operator with both evaluated
+    inside every scan (DIFFMA_HOIST_GATE=0, the upstream arrangement): outputs and all gradients agree to rounding."""
+    from diffma_amd import selective_scan_interface as ssi
+    from diffma_amd import tools
+
+    Bsz, L, Din, N, R = 3, 49, 256, 16, 16
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(gpu)
+    xz = mk(Bsz, L, 2 * Din).to(dtype)
+    conv_w, conv_b = mk(Din, 1, 4, sc=0.5), mk(Din, sc=0.1)
+    Wx, Wdt, dt_b = mk(R + 2 * N, Din, sc=Din ** -0.5), mk(Din, R, sc=R ** -0.5), mk(Din, sc=0.5)
+    A, Dsk = -(torch.rand(Din, N, generator=g) * 4 + 0.2).to(gpu), mk(Din)
+    sp = tools.spiral(7)
+    idx = torch.tensor([list(range(L)), sp[0][2], sp[0][3]], dtype=torch.int32, device=gpu)
+    dy = mk(Bsz, L, Din).to(dtype)
+
+    def run(hoist):
+        monkeypatch.setattr(ssi, "HOIST_GATE", hoist)
+        leaves = [t.clone().requires_grad_(True) for t in (xz, conv_w, conv_b, Wx, Wdt, dt_b, A, Dsk)]
+        y = ssi.spiral_ssm(*leaves[:6], leaves[6], leaves[7], idx)
+        y.backward(dy)
+        return [y.detach().float()] + [t.grad.float() for t in leaves]
+
+    a, b = run(True), run(False)
+    tol = dict(rtol=2e-4, atol=2e-4) if dtype == torch.float32 else dict(rtol=4e-2, atol=4e-2)
+    for name, p, q in zip(["y", "dxz", "dconv_w", "dconv_b", "dWx", "dWdt", "ddt_bias", "dA", "dD"], a, b):
+        sc = max(1.0, float(q.abs().max()))
+        torch.testing.assert_close(p, q, rtol=tol["rtol"], atol=tol["atol"] * sc, msg=lambda m, name=name: f"{name}: {m}")
