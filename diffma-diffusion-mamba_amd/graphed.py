@@ -134,6 +134,13 @@ class GraphedTrainStep:
         if self.split and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("the two-graph (data-parallel) step needs an initialised process group")
         self._gp = [p for p in model.parameters() if p.requires_grad]
+        # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
+        # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
+        # gradients inside the graph and handed to the fused AdamW, which then leaves weights, moments and step count alone.
+        # `skipped` counts such steps; the host reads it when it logs.  (The EMA line still runs: it blends towards weights that
+        # did not move, a 1 - decay step in place -- it cannot be poisoned.)
+        self._one = torch.ones((), device=z.device)
+        self.skipped = torch.zeros(1, device=z.device)
         with torch.cuda.device(z.device):
             side = torch.cuda.Stream(device=z.device)
             side.wait_stream(torch.cuda.current_stream(z.device))
@@ -172,13 +179,22 @@ class GraphedTrainStep:
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             loss = self.diffusion.training_losses(self.model, self.sz, self.st, dict(y=self.sy, y2=self.sy2, w=self.sw))["loss"].mean()
         loss.backward()
-        self.opt.step()
-        if self.ema is not None:
-            with torch.no_grad():
-                torch._foreach_mul_(self._ep, self.decay)
-                torch._foreach_add_(self._ep, self._mp, alpha=1 - self.decay)
+        found = torch.zeros(1, device=self.sz.device)
+        grads = [p.grad for p in self._gp if p.grad is not None]
+        if grads:
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found, self._one)      # inv_scale 1: a pure check
+        self._guarded_update(found)
         self.opt.zero_grad(set_to_none=True)
         return loss.detach()
+
+    def _guarded_update(self, found):
+        self.opt.grad_scale, self.opt.found_inf = None, found          # read by the fused AdamW: found_inf = 1 -> no update
+        self.opt.step()
+        with torch.no_grad():
+            self.skipped += found
+            if self.ema is not None:
+                torch._foreach_mul_(self._ep, self.decay)
+                torch._foreach_add_(self._ep, self._mp, alpha=1 - self.decay)
 
     # ---- the data-parallel form: graph 1 | all-reduce | graph 2 ----------------------------------------------------------
     def _fwd_bwd(self):
@@ -204,11 +220,8 @@ class GraphedTrainStep:
                 else:
                     p.grad.copy_(g)
                 off += n
-        self.opt.step()
-        if self.ema is not None:
-            with torch.no_grad():
-                torch._foreach_mul_(self._ep, self.decay)
-                torch._foreach_add_(self._ep, self._mp, alpha=1 - self.decay)
+            found = (~torch.isfinite(self.flat).all()).float().reshape(1)     # after the all-reduce: the same on every rank
+        self._guarded_update(found)
 
     def step(self, z, t, y, y2, w):
         self.sz.copy_(z)

@@ -211,10 +211,12 @@ def main(args):
                 train_steps += 1
                 log_steps += 1
                 if train_steps % args.log_every == 0:           # the only host sync of the graphed loop
-                    lv = loss.item()
-                    if not math.isfinite(lv):
-                        raise FloatingPointError(f"non-finite loss at step {train_steps} (a graphed step cannot skip its update)")
-                    running_loss = lv * log_steps               # the log line shows the latest loss instead of a running mean
+                    # non-finite steps were dropped ON THE DEVICE (found_inf from the all-reduced gradients, the same decision on
+                    # every rank: graphed.GraphedTrainStep._guarded_update); the host only reports them
+                    lv, nskip = loss.item(), int(graphed.skipped.item())
+                    if nskip:
+                        logger.info(f"nan......      ignore losses......   ({nskip} graphed steps skipped so far)")
+                    running_loss = (lv if math.isfinite(lv) else 0.0) * log_steps   # the log line shows the latest loss instead of a running mean
             else:
                 with torch.autocast(device.type, dtype=amp, enabled=amp is not None):
                     loss = diffusion.training_losses(ddp, z, t, dict(y=y, y2=y2, w=w))["loss"].mean()
@@ -236,6 +238,7 @@ def main(args):
                             p_.grad = None
                         else:
                             p_.grad.copy_(g_)
+                    continue                                 # like the reference (train.py:254-256): the step is not counted, no log / ckpt check
                 else:
                     scaler.scale(loss).backward()
                     if train_steps % args.accumulation_steps == 0:
@@ -245,7 +248,7 @@ def main(args):
                         opt.zero_grad(set_to_none=True)
                     running_loss += loss_host
                     log_steps += 1
-                train_steps += 1                             # a skipped step still counts: --max-steps / ckpt / log checks run
+                train_steps += 1
             if train_steps % args.log_every == 0:
                 if device.type == "cuda":
                     torch.cuda.synchronize()
