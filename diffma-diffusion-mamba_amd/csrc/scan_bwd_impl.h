@@ -26,6 +26,10 @@
 #include <type_traits>
 #include "dm_common.h"
 
+#ifndef DM_K2_EXP
+#define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
+#endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads
+
 namespace dm {
 
 constexpr int BWD_CK = 8;      // steps per staging chunk (B/C rows and dB/dC partials go through LDS once per chunk)
@@ -136,6 +140,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
     constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M % 16 == 0;   // dB/dC lane-group sums on the matrix pipe
+    // KEEPA: the decay factors a = exp(delta*A) the recompute pass evaluates for the first SUB-1 steps of a sub-chunk are kept for
+    // the reverse sweep as fp16 pairs (8 VGPRs per step instead of 16 v_exp_f32 + 8 v_pk_mul_f32 evaluated a second time); the
+    // sweep multiplies with them through v_fma_mix_f32.  16-bit I/O only: a in (0, 1] rounded to 11 bits is far inside what the
+    // I/O rounding of the gradients leaves (the fp32 instantiation keeps evaluating them exactly).
+#ifndef DM_K2_KEEPA
+#define DM_K2_KEEPA 0          // recompute steps whose factors are kept (the LAST ones of the pass); measured (MI355X, nseq 1536): 0: 2717-2745 us, 1: 2702-2719, 2: 2765-2768, 3: spills, 4370 -- the kernel is not limited by its VALU instruction count (profiles/r03_k2_experiments.txt), so this is OFF
+#endif
+    constexpr bool KEEPA = DM_K2_KEEPA > 0 && sizeof(T) == 2 && N == 16 && SPLIT == 1 && !ASH && DMODE == 2;
+    constexpr int KEEP0 = SUB - 1 - DM_K2_KEEPA;               // first kept step of a sub-chunk
+    typedef _Float16 a_h2 __attribute__((ext_vector_type(2)));
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
@@ -286,6 +300,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     };
     uint32_t hnext[H0W];                                         // state entering the sub-chunk after the current chunk
     load_state(nchunk * (CK / SUB), hnext);
+    // PFCK: the raw checkpoint words of a chunk are requested one chunk ahead (packed checkpoints only: 16 VGPRs); without it they
+    // are requested at the top of the chunk and the first sub-chunk waits for them
+#ifndef DM_K2_PFCK
+#define DM_K2_PFCK 1          // measured -0.6 % (2588-2592 -> 2572-2574 us)
+#endif
+    constexpr bool PFCK = DM_K2_PFCK && CK_PACKED && N == 16 && SPLIT == 1;
+    uint32_t h0pf[CK / SUB][H0W];
+    if constexpr (PFCK) {
+#pragma unroll
+        for (int sc = 0; sc < CK / SUB; ++sc) load_state((nchunk - 1) * (CK / SUB) + sc, h0pf[sc]);
+    }
 
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
@@ -321,8 +346,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         // ---- state slices entering the chunk's sub-chunks (sub-chunk 0 of the sequence and sub-chunks past the end: 0) ----
         // (packed checkpoints stay raw until the sub-chunk starts: unpacking here would put a vmcnt(0) right behind every load)
         uint32_t h0w[CK / SUB][H0W];
+        if constexpr (PFCK) {
 #pragma unroll
-        for (int sc = 0; sc < CK / SUB; ++sc) load_state(ch * (CK / SUB) + sc, h0w[sc]);
+            for (int sc = 0; sc < CK / SUB; ++sc) {
+#pragma unroll
+                for (int k = 0; k < H0W; ++k) h0w[sc][k] = h0pf[sc][k];
+                if (ch > 0) load_state((ch - 1) * (CK / SUB) + sc, h0pf[sc]);       // lands while this chunk computes
+            }
+        } else {
+#pragma unroll
+            for (int sc = 0; sc < CK / SUB; ++sc) load_state((DM_K2_EXP & 4) ? -1 : ch * (CK / SUB) + sc, h0w[sc]);
+        }
 
 #pragma unroll
         for (int j = 0; j < CK; ++j) {
@@ -334,9 +368,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             gg[j] = (valid && active) ? gg[j] : 0.f;
         }
         // one forward step of the slice: h <- a*h + B*dl*u   (used by all three recompute passes)
-        auto fwd_step = [&](f32x2(&h)[NPL], int j) {
+        uint32_t apk[KEEPA ? DM_K2_KEEPA : 1][KEEPA ? NPL : 1];    // [kept step][state pair]: fp16 pairs
+        auto fwd_step = [&](f32x2(&h)[NPL], int j, int keep) {
             float Bv[NS];
             const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
+            if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) Bv[k] = opaque(1.0f); } else
             lds_ld_vec<NS>(Bv, brow);
             const float dlo = opaque(dl[j]);
             const float du = dlo * uu[j];
@@ -352,6 +388,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     a.x = fast_exp2(t.x);
                     a.y = fast_exp2(t.y);
                 }
+                if constexpr (KEEPA) { if (keep >= KEEP0) apk[keep - KEEP0][k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, a_h2)); }
                 f32x2 bb;
                 bb.x = Bv[2 * k];
                 bb.y = Bv[2 * k + 1];
@@ -366,11 +403,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             f32x2 h[NPL];
             unpack_state(h, h0w[sc]);
             f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
+            // LAZY0: hs[0] IS the checkpoint, whose raw words stay live anyway (they are the end state of the next sub-chunk to be
+            // processed): with packed checkpoints it is unpacked again when the sweep reaches step 0 (16 shifts / ands per
+            // sub-chunk) instead of occupying 16 VGPRs through the whole sweep -- the registers the kept decay factors live in
+            constexpr bool LAZY0 = KEEPA && CK_PACKED;
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) hs[i][k] = h[k];
-                if (i < SUB - 1) fwd_step(h, sc * SUB + i);
+                for (int k = 0; k < NPL; ++k) { if (!(LAZY0 && i == 0)) hs[i][k] = h[k]; }
+                if (i < SUB - 1) fwd_step(h, sc * SUB + i, i);
             }
             // the state after the sub-chunk's last step is the next sub-chunk's checkpoint: one recomputed step less
             if (sc == CK / SUB - 1) unpack_state(h, hnext);
@@ -384,8 +425,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const int l = valid ? lraw : L - 1;
                 float Bv[NS], Cv[NS];
                 const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);
+                if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
                 lds_ld_vec<NS>(Bv, brow);
-                lds_ld_vec<NS>(Cv, brow + N);
+                lds_ld_vec<NS>(Cv, brow + N); }
                 const float g = gg[j];
                 float sz = 1.f, gy = g;
                 if (HAS_Z) {
@@ -405,19 +447,34 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
                     cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
                     f32x2 a;
+                    const bool kept = KEEPA && i < SUB - 1 && i >= KEEP0;      // compile-time after unrolling
                     if (ASH) {
                         a = (f32x2){a_rev, a_rev};
-                    } else {
+                    } else if (!kept) {
                         const f32x2 t = A2[k] * dlo;
                         a.x = fast_exp2(t.x);
                         a.y = fast_exp2(t.y);
                     }
                     const f32x2 hj = h[k];
-                    const f32x2 hp = hs[i][k];
-                    yp2 += cc * hj;
+                    f32x2 hp;
+                    if (LAZY0 && i == 0) {
+                        uint32_t w = h0w[sc][k];
+                        asm volatile("" : "+v"(w));              // unpack HERE (an early unpack would re-occupy the registers)
+                        hp.x = __uint_as_float(w << 16);
+                        hp.y = __uint_as_float(w & 0xffff0000u);
+                    } else {
+                        hp = hs[i][k];
+                    }
+                    if (HAS_Z) yp2 += cc * hj;
                     const f32x2 G = cc * gy + carry[k];          // dL/dh_j
                     const f32x2 dCp = hj * gy;
-                    carry[k] = a * G;                            // a_j * dL/dh_j, flows to step j-1
+                    if (kept) {
+                        const a_h2 ah = __builtin_bit_cast(a_h2, apk[kept ? i - KEEP0 : 0][KEEPA ? k : 0]);
+                        carry[k].x = (float)ah.x * G.x;          // v_fma_mix_f32: the fp16 operand is converted in the multiplier
+                        carry[k].y = (float)ah.y * G.y;
+                    } else {
+                        carry[k] = a * G;                        // a_j * dL/dh_j, flows to step j-1
+                    }
                     const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
@@ -447,14 +504,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     dbias_acc += ddl;
                 }
                 if (valid && active && q == 0) {
-                    bio<T>::st_cv(r_du, vo, l * sl_du, duv);
-                    bio<T>::st_cv(r_ddt, vo, l * sl_ddt, ddl);
+                    if (!(DM_K2_EXP & 8) || duv == 123.456f) bio<T>::st_cv(r_du, vo, l * sl_du, duv);
+                    if (!(DM_K2_EXP & 8) || ddl == 123.456f) bio<T>::st_cv(r_ddt, vo, l * sl_ddt, ddl);
                     if (HAS_Z) {
                         const float dzv = g * ypre * sz * (1.0f + zz[j] * (1.0f - sz));
                         bio<T>::st_cv(r_dz, vo, zrow[j] * sl_dz, dzv);
                     }
                 }
-                if constexpr (MFMA_RED) {
+                if constexpr (DM_K2_EXP & 1) {
+                } else if constexpr (MFMA_RED) {
 #pragma unroll
                     for (int g16 = 0; g16 < M / 16; ++g16) {   // 16 values (8 pairs) per pair of MFMAs; register r of group g16 = value 16*g16 + 4*(lane>>4) + r
                         const u32x4_t lo = {pk_all[8 * g16], pk_all[8 * g16 + 1], pk_all[8 * g16 + 2], pk_all[8 * g16 + 3]};
@@ -472,10 +530,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         }
 #pragma unroll
         for (int k = 0; k < H0W; ++k) hnext[k] = h0w[0][k];
-        __syncthreads();
-        flush_dbc(ch);
+        if (!(DM_K2_EXP & 2)) __syncthreads();
+        if (!(DM_K2_EXP & 3)) flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);
-        __syncthreads();
+        if (!(DM_K2_EXP & 2)) __syncthreads();
         buf ^= 1;
     }
     if (active) {

@@ -82,6 +82,25 @@ def main():
             print(json.dumps(dict(kernel="scan_fwd_idx_ckpt", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
             t = timeit(lambda: hip_ops.scan_bwd(u, delta, A, Bm, Cm, Dp, zb, bias, doutb, ckpt, True, ckpt_every=K, **kw), args.iters)
             print(json.dumps(dict(kernel="scan_bwd_idx(+partial sums)", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
+        if want("scan_hoist") and S % 3 == 0:
+            # the mixer's call since round 3: gate and softplus hoisted -- no z, delta already activated, pre-gated gradient
+            Bd = S // 3
+            K = hip_ops.SCAN_CKPT_EVERY
+            idx = torch.stack([torch.arange(L), torch.randperm(L), torch.randperm(L)]).to(torch.int32).to(dev)
+            act = torch.nn.functional.softplus(delta.float() + bias).to(dt)
+            doutb = torch.randn(Bd, L, Dm, device=dev).to(dt)
+            ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Dm, dt, dev)
+            kw = dict(z_row_index=idx, out_row_index=idx, batch_per_dir=Bd, delta_activated=True)
+            t = timeit(lambda: hip_ops.scan_fwd(u, act, A, Bm, Cm, Dp, None, bias, True, out=out, ckpt=ckpt, ckpt_every=K, **kw), args.iters)
+            print(json.dumps(dict(kernel="scan_fwd_hoisted_ckpt", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
+            t = timeit(lambda: hip_ops.scan_bwd(u, act, A, Bm, Cm, Dp, None, bias, doutb, ckpt, True, ckpt_every=K, **kw), args.iters)
+            print(json.dumps(dict(kernel="scan_bwd_hoisted(+partial sums)", S=S, dtype=args.dtype, us=t * 1e6)), flush=True)
+            tm = hip_ops.KernelTimer()                          # the kernel alone (events around the C-ABI launch)
+            prev = hip_ops.set_timer(tm)
+            for _ in range(args.iters):
+                hip_ops.scan_bwd(u, act, A, Bm, Cm, Dp, None, bias, doutb, ckpt, True, ckpt_every=K, **kw)
+            hip_ops.set_timer(prev)
+            print(json.dumps(dict(kernel="scan_bwd_hoisted_kernel_only", S=S, dtype=args.dtype, us=tm.summary()["dm_selective_scan_bwd"]["avg_us"])), flush=True)
         if not (want("conv") or want("merge") or want("copy")):
             continue
         # conv (3 directions) : reads x once per direction, writes 3 outputs
