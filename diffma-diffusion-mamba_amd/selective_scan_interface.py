@@ -425,7 +425,7 @@ class _SpiralSSDFn(torch.autograd.Function):
             # but the operands saved for the backward (which recomputes the score tiles)
             ydir = hip_ops.ssd_fwd(x, Bm, Cm, dt_tok, z, A_h, D_h, dt_bias_h, z_row_index=scan_index, out_row_index=scan_index,
                                    batch_per_dir=Bsz)
-            out, rstd = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+            out, rstd = _SpiralSSDFn._norm_merge(ydir, norm_w, eps, ndir, Bsz, L, Din)
             if need_grad:
                 ctx.ssd = True
                 ctx.save_for_backward(zxbcdt, conv_w, conv_b, xBC, A_h, D_h, dt_bias_h, ydir, rstd, norm_w, scan_index)
@@ -441,10 +441,26 @@ class _SpiralSSDFn(torch.autograd.Function):
         ckpt = hip_ops.alloc_scan_ckpt(S, L, N, Din, zxbcdt.dtype, zxbcdt.device) if need_grad else None
         ydir = hip_ops.scan_fwd(x, delta, A, Bm, Cm, Dskip, z, dt_bias, True, z_row_index=scan_index, out_row_index=scan_index,
                                 batch_per_dir=Bsz, ckpt=ckpt, a_shared=True)     # token order, gated; one decay per head
-        out, rstd = hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+        out, rstd = _SpiralSSDFn._norm_merge(ydir, norm_w, eps, ndir, Bsz, L, Din)
         ctx.save_for_backward(zxbcdt, conv_w, conv_b, xBC, delta, A, Dskip, dt_bias, ckpt, ydir, rstd, norm_w, scan_index, scan_index_inv)
         ctx.meta = (Din, N, H, P, eps, dt_bias_h.dtype, A_h.dtype, D_h.dtype)
         return out
+
+    @staticmethod
+    def _norm_merge(ydir, norm_w, eps, ndir, Bsz, L, Din):
+        """Gated RMSNorm of every direction + merge; norm_w None (the operator called with rmsnorm_weight=None, one direction):
+        the gated scan output itself."""
+        if norm_w is None:
+            if ndir != 1:
+                raise NotImplementedError("the un-normalised Mamba-2 core is wired for one direction (the reference-facing operator)")
+            return ydir.view(Bsz, L, Din), None
+        return hip_ops.rmsnorm_merge_fwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps)
+
+    @staticmethod
+    def _norm_merge_bwd(ydir, norm_w, eps, rstd, dout, ndir, Bsz, L, Din):
+        if norm_w is None:
+            return dout.contiguous().view(1, Bsz, L, Din), None
+        return hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)
 
     @staticmethod
     def backward(ctx, dout):
@@ -458,7 +474,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         dt_ = zxbcdt.dtype
         if dout.dtype != dt_:
             dout = dout.to(dt_)
-        dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
+        dyd, dnorm_w = _SpiralSSDFn._norm_merge_bwd(ydir, norm_w, eps, rstd, dout, ndir, Bsz, L, Din)                # [ndir, B, L, Din]
         dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         _, ddelta, dzs, _, _, dA, dD, dbias = hip_ops.scan_bwd(
@@ -482,7 +498,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         dD_h = dD.view(H, P).sum(-1)
         dbias_h = dbias.view(H, P).sum(-1)
         return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
-                dbias_h.to(bias_dt), dA_h.to(A_dt), dD_h.to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
+                dbias_h.to(bias_dt), dA_h.to(A_dt), dD_h.to(D_dt), None if dnorm_w is None else dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
 
 
     @staticmethod
@@ -495,7 +511,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         dt_ = zxbcdt.dtype
         if dout.dtype != dt_:
             dout = dout.to(dt_)
-        dyd, dnorm_w = hip_ops.rmsnorm_merge_bwd(ydir.view(ndir, Bsz, L, Din), norm_w, eps, rstd, dout)            # [ndir, B, L, Din]
+        dyd, dnorm_w = _SpiralSSDFn._norm_merge_bwd(ydir, norm_w, eps, rstd, dout, ndir, Bsz, L, Din)                # [ndir, B, L, Din]
         dxBC = torch.empty((S, L, Cx), dtype=dt_, device=zxbcdt.device)
         x, Bm, Cm = xBC[..., :Din], xBC[..., Din:Din + N], xBC[..., Din + N:]
         _, dzs, dbc, ddt, dad = hip_ops.ssd_bwd(
@@ -511,7 +527,7 @@ class _SpiralSSDFn(torch.autograd.Function):
         ddt_tok = ddt4[0] if ndir == 1 else ddt4.sum(0)
         dzx[..., Din + Cx:].copy_(ddt_tok)
         return (dzx, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
-                dad[2].to(bias_dt), dad[0].to(A_dt), dad[1].to(D_dt), dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
+                dad[2].to(bias_dt), dad[0].to(A_dt), dad[1].to(D_dt), None if dnorm_w is None else dnorm_w.to(norm_w.dtype), None, None, None, None, None, None)
 
 
 def spiral_ssd(zxbcdt, conv_w, conv_b, dt_bias, A, D, norm_w, eps, scan_index, scan_index_inv, d_inner, d_state):
@@ -574,24 +590,18 @@ def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias
     Bsz, L, _ = zxbcdt.shape
     if chunk_size < L:
         raise NotImplementedError("multi-chunk SSD (chunk_size < seqlen) is never reached by DiffMa")
+    if rmsnorm_weight is not None and norm_before_gate:
+        raise NotImplementedError("norm_before_gate=True (norm, then gate) is not wired; DiffMa uses norm_before_gate=False (block/mamba2.py:349)")
     H = D.shape[0]
     dim = H * headdim
     N = (zxbcdt.shape[-1] - 2 * dim - H) // 2
     if zxbcdt.stride(-1) != 1:
         zxbcdt = zxbcdt.contiguous()
+    # ONE autograd node, the same one the Mamba2 module runs with three directions: conv (K3), the single-chunk SSD core on the
+    # matrix pipe (dm_ssd_fwd / dm_ssd_bwd) when the shape allows it -- 16-bit I/O, headdim 64, d_state 16, 16-byte aligned rows --
+    # else the A-shared selective scan, then the gated RMSNorm (dm_rmsnorm_merge_*, one slab) when rmsnorm_weight is given.
     ident = torch.arange(L, device=zxbcdt.device, dtype=torch.int32)[None]
-    xBC = gather_conv1d(zxbcdt[..., dim:2 * dim + 2 * N], conv1d_weight, conv1d_bias, ident)
-    delta = zxbcdt[..., 2 * dim + 2 * N:].repeat_interleave(headdim, dim=-1)
-    A2 = A.float().repeat_interleave(headdim)[:, None].expand(dim, N)
-    y = indexed_scan(xBC[..., :dim], delta, A2, xBC[..., dim:dim + N], xBC[..., dim + N:], D.float().repeat_interleave(headdim),
-                     zxbcdt[..., :dim] if (rmsnorm_weight is None or not norm_before_gate) else None, dt_bias.float().repeat_interleave(headdim),
-                     ident, Bsz)[0]
-    if rmsnorm_weight is not None:
-        yf = y.float()
-        yf = yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + rmsnorm_eps) * rmsnorm_weight.float()
-        if norm_before_gate:
-            yf = yf * F.silu(zxbcdt[..., :dim].float())
-        y = yf.to(zxbcdt.dtype)
+    y = spiral_ssd(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, rmsnorm_weight, rmsnorm_eps, ident, ident, dim, N)
     if outproj_weight is not None:
         y = F.linear(y, outproj_weight.to(y.dtype), outproj_bias)
     return y

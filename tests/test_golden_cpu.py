@@ -140,6 +140,29 @@ def test_oracle_model_matches_reference_output():
         np.testing.assert_allclose(blocks[k].numpy(), g[f"act.block{k}"], rtol=1e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("depth", [9, 13])
+def test_oracle_deep_model_matches_reference_output(depth):
+    """G12: depth 9 / 13 (hidden 32) through the reference class -- spiral lists 8..15, the wrap of the list index at block 8
+    (model.py:147-150) and the skip pairs of odd / deep stacks (model.py:286-295), which depth 4 / 5 never reach."""
+    from oracle.model_ref import diffma_forward_ref
+
+    g = load("g12_deep_tiny_diffma.npz")
+    tag = f"d{depth}"
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}.sd.")}
+    inp = {k: torch.from_numpy(g[f"{tag}.{k}"]) for k in ("x", "t", "y", "y2", "w")}
+    out, blocks = diffma_forward_ref(sd, inp["x"], inp["t"], inp["y"], inp["y2"], inp["w"], patch_size=2, depth=depth,
+                                     dtype=torch.float64, return_blocks=True)
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}.out"], rtol=1e-4, atol=5e-6)
+    for k in range(depth):
+        np.testing.assert_allclose(blocks[k].numpy(), g[f"{tag}.act.block{k}"], rtol=1e-4, atol=5e-5)
+    # the product model takes the same state dict strictly (names, order, shapes)
+    from diffma_amd.model import DiffMa
+
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=32, depth=depth, d_state=16)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+
+
 def test_product_model_has_reference_state_dict_layout():
     from diffma_amd.model import DiffMa
 

@@ -45,6 +45,34 @@ def test_diffma_forward_matches_reference_fp32(gpu):
         assert rel_l2(acts[k], torch.from_numpy(g[f"act.block{k}"])) <= 1e-3
 
 
+@pytest.mark.parametrize("depth", [9, 13])
+def test_deep_diffma_forward_matches_reference(gpu, depth):
+    """G12 (reference `DiffMa` class at depth 9 / 13, hidden 32): spiral lists 8..15, the wrap at block 8 (model.py:147-150)
+    and the odd / deep skip pairs (model.py:286-295) on the device, output and every block activation."""
+    from diffma_amd.model import DiffMa
+
+    g = np.load(os.path.join(G, "g12_deep_tiny_diffma.npz"))
+    tag = f"d{depth}"
+    sd = {k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(f"{tag}.sd.")}
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=32, depth=depth, d_state=16)
+    net.load_state_dict(sd)
+    net = net.to(gpu).eval()
+    inp = {k: torch.from_numpy(g[f"{tag}.{k}"]).to(gpu) for k in ("x", "t", "y", "y2", "w")}
+    acts = {}
+    hooks = [b.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().cpu())) for k, b in enumerate(net.blocks)]
+    with torch.no_grad():
+        out = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).cpu()
+    for h in hooks:
+        h.remove()
+    ref = torch.from_numpy(g[f"{tag}.out"])
+    assert rel_l2(out, ref) <= 1e-3, rel_l2(out, ref)
+    for k in range(depth):
+        assert rel_l2(acts[k], torch.from_numpy(g[f"{tag}.act.block{k}"])) <= 1e-3, (k, rel_l2(acts[k], torch.from_numpy(g[f"{tag}.act.block{k}"])))
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        out16 = net(inp["x"], inp["t"], y=inp["y"], y2=inp["y2"], w=inp["w"]).float().cpu()
+    assert rel_l2(out16, ref) <= 3e-2, rel_l2(out16, ref)
+
+
 def test_diffma_forward_bf16_autocast(gpu):
     g, sd, net, inp = _g5(gpu)
     with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
@@ -763,3 +791,89 @@ def test_mamba2_mixer_training_on_the_matrix_pipe(gpu, monkeypatch, n):
     assert rel_l2(y, y2) <= 2e-2 and rel_l2(gx, gx2) <= 3e-2
     for k in gp:
         assert rel_l2(gp[k], gp2[k]) <= 4e-2, (k, rel_l2(gp[k], gp2[k]))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE.json's configurations at their REAL depth and width: the factory model, batch 1, one forward on
+# the device against the CPU oracle (functional restatement on the same state dict; fp32, rel-L2 <= 1e-3).
+# ------------------------------------------------------------------------------------------------------------------
+def _rerandomize(net, seed):
+    """The reference init zeroes the output layers / adaLN / dt_proj.bias (SURVEY.md A.4-1,3): the stock output is exactly 0."""
+    gen = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if p.requires_grad and float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+            if name.endswith("dt_proj.bias"):
+                dt = torch.exp(torch.rand(p.shape, generator=gen) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+                p.copy_(dt + torch.log(-torch.expm1(-dt)))
+
+
+@pytest.mark.parametrize("name,kw", [("DiffMa-B/4", {}), ("DiffMa-L/2", {}), ("DiffMa-XL/2", dict(use_mamba2=True)), ("DiffMa-XXL/2", {})])
+def test_baseline_config_models_match_oracle_at_full_size(gpu, name, kw):
+    from diffma_amd.model import DiffMa_models
+    from oracle.model_ref import diffma_forward_ref
+
+    torch.manual_seed(11)
+    net = DiffMa_models[name](input_size=28, dt_rank=16, d_state=16, **kw).eval()
+    _rerandomize(net, 12)
+    patch, depth = int(name.split("/")[1]), len(net.blocks)
+    L = (28 // patch) ** 2
+    g = torch.Generator().manual_seed(13)
+    x, y, y2 = torch.randn(1, 4, 28, 28, generator=g), torch.randn(1, 512, generator=g), torch.randn(1, L, 512, generator=g)
+    w = torch.sigmoid(torch.randn(1, L, 1, generator=g))
+    t = torch.tensor([437])
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    ref, blocks = diffma_forward_ref(sd, x, t, y, y2, w, patch_size=patch, depth=depth, dtype=torch.float32, return_blocks=True,
+                                     use_mamba2=kw.get("use_mamba2", False))
+    net = net.to(gpu)
+    acts = {}
+    hooks = [b.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().cpu())) for k, b in enumerate(net.blocks)]
+    with torch.no_grad():
+        out = net(x.to(gpu), t.to(gpu), y=y.to(gpu), y2=y2.to(gpu), w=w.to(gpu)).cpu()
+    for h in hooks:
+        h.remove()
+    assert float(ref.abs().mean()) > 1e-3                          # a live output, not the zero-init one
+    assert rel_l2(out, ref) <= 1e-3, rel_l2(out, ref)
+    for k in (0, depth // 2, depth - 1):                           # first, the block where the long skips start, last
+        assert rel_l2(acts[k], blocks[k]) <= 1e-3, (k, rel_l2(acts[k], blocks[k]))
+
+
+@pytest.mark.parametrize("rms", [True, False])
+def test_mamba_split_conv1d_scan_combined_runs_on_the_matrix_pipe(gpu, monkeypatch, rms):
+    """Route A of INTEGRATION.md for Mamba-2: the reference-facing operator (block/mamba2.py:392-410) at the DiffMa-XL/2 mixer
+    width (d_inner 1024, 16 heads of 64, d_state 16) in bf16 must reach csrc/ssd.hip / csrc/ssd_bwd.hip (no scan launch), with
+    and without the gated RMSNorm; output and every gradient against fp64 autograd through the oracle restatement."""
+    from diffma_amd import hip_ops
+    from diffma_amd.selective_scan_interface import mamba_split_conv1d_scan_combined
+    from oracle.mamba2_ref import mamba_split_conv1d_scan_combined_ref
+
+    calls = {"ssd_fwd": 0, "ssd_bwd": 0, "scan_fwd": 0, "scan_bwd": 0}
+    for name in calls:
+        real = getattr(hip_ops, name)
+        monkeypatch.setattr(hip_ops, name, (lambda real, name: lambda *a, **k: (calls.__setitem__(name, calls[name] + 1), real(*a, **k))[1])(real, name))
+    gen = torch.Generator().manual_seed(21)
+    B, L, H, P, N, dm = 2, 196, 16, 64, 16, 512
+    dim = H * P
+    mk = lambda *s, sc=1.0: torch.randn(*s, generator=gen) * sc
+    zx = mk(B, L, 2 * dim + 2 * N + H).bfloat16()
+    cw, cb = mk(dim + 2 * N, 4, sc=0.4), mk(dim + 2 * N, sc=0.1)
+    dt_bias, A, D = mk(H, sc=0.5), -(torch.rand(H, generator=gen) * 4 + 0.5), mk(H)
+    nw, ow = 1 + mk(dim, sc=0.1), mk(dm, dim, sc=dim ** -0.5)
+    dy = mk(B, L, dm)
+    kw = dict(chunk_size=256, seq_idx=None, activation="silu", rmsnorm_eps=1e-5, outproj_bias=None, headdim=P, ngroups=1, norm_before_gate=False)
+    leaves = [t.to(gpu).requires_grad_(True) for t in (zx, cw, cb, dt_bias, A, D, nw, ow)]
+    got = mamba_split_conv1d_scan_combined(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], D=leaves[5],
+                                           rmsnorm_weight=leaves[6] if rms else None, outproj_weight=leaves[7].bfloat16(), **kw)
+    (got.float() * dy.to(gpu)).sum().backward()
+    assert calls == {"ssd_fwd": 1, "ssd_bwd": 1, "scan_fwd": 0, "scan_bwd": 0}, calls
+    ref_leaves = [t.float().double().clone().requires_grad_(True) for t in (zx, cw, cb, dt_bias, A, D, nw, ow)]
+    ref = mamba_split_conv1d_scan_combined_ref(ref_leaves[0], ref_leaves[1], ref_leaves[2], ref_leaves[3], ref_leaves[4], D=ref_leaves[5],
+                                               rmsnorm_weight=ref_leaves[6] if rms else None, outproj_weight=ref_leaves[7], **kw)
+    (ref * dy.double()).sum().backward()
+    assert got.shape == (B, L, dm) and rel_l2(got.float().cpu(), ref.detach()) <= 2e-2, rel_l2(got.float().cpu(), ref.detach())
+    names = ["zxbcdt", "conv_w", "conv_b", "dt_bias", "A", "D", "norm_w", "outproj_w"]
+    for k, (a, b) in enumerate(zip(leaves, ref_leaves)):
+        if names[k] == "norm_w" and not rms:
+            continue
+        assert rel_l2(a.grad.float().cpu(), b.grad) <= 4e-2, (names[k], rel_l2(a.grad.float().cpu(), b.grad))

@@ -272,14 +272,55 @@ def main():
             print("G11 step", step, "loss", float(loss.detach()))
         np.savez_compressed(os.path.join(OUT, "g11_train_step.npz"), **g)
 
+
+    # ---- G12 deep tiny denoisers (hidden 32) through the reference class: spiral lists 8..15, the wrap of the list index at
+    # block 8 (model.py:147-150) and the long-skip pairs of odd and > 8 depths (model.py:286-295) -- depth 4 / 5 (G5, G9) reach
+    # neither.  Operator = oracle stub, as in G5.
+    def g12():
+        g = {}
+        for depth in (9, 13):
+            torch.manual_seed(4000 + depth)
+            net = ref_model.DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=32, depth=depth, d_state=16)
+            gen = torch.Generator().manual_seed(500 + depth)
+            with torch.no_grad():
+                for name, p in net.named_parameters():
+                    if p.requires_grad and float(p.abs().max()) == 0.0:
+                        p.copy_(torch.randn(p.shape, generator=gen) * 0.05)
+                    if name.endswith("dt_proj.bias"):
+                        dt = torch.exp(torch.rand(p.shape, generator=gen) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+                        p.copy_(dt + torch.log(-torch.expm1(-dt)))
+                    if name.endswith("A_log") or name.endswith(".D"):
+                        p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+            net.eval()
+            N = 2
+            x = torch.randn(N, 4, 8, 8, generator=gen)
+            t = torch.tensor([5, 731])
+            y = torch.randn(N, 32, generator=gen)
+            y2 = torch.randn(N, 16, 32, generator=gen)
+            w = torch.sigmoid(torch.randn(N, 16, 1, generator=gen))
+            acts = {}
+            hooks = [blk.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().numpy())) for k, blk in enumerate(net.blocks)]
+            with torch.no_grad():
+                out = net(x, t, y=y, y2=y2, w=w)
+            for h in hooks:
+                h.remove()
+            tag = f"d{depth}"
+            g.update({f"{tag}.sd.{k}": v.numpy() for k, v in net.state_dict().items()})
+            g.update({f"{tag}.x": x.numpy(), f"{tag}.t": t.numpy(), f"{tag}.y": y.numpy(), f"{tag}.y2": y2.numpy(), f"{tag}.w": w.numpy(),
+                      f"{tag}.out": out.numpy()})
+            g.update({f"{tag}.act.block{k}": v for k, v in acts.items()})
+            print("G12 depth", depth, "params", sum(p.numel() for p in net.parameters()), "out abs mean", float(out.abs().mean()))
+        np.savez_compressed(os.path.join(OUT, "g12_deep_tiny_diffma.npz"), **g)
+
     only = [a for a in sys.argv[1:] if a.startswith("--only-")]
     if only:
         for a in only:
-            {"--only-g9": g9, "--only-g10": g10, "--only-g8b": g8b, "--only-g11": g11}[a]()
+            {"--only-g9": g9, "--only-g10": g10, "--only-g8b": g8b, "--only-g11": g11, "--only-g12": g12}[a]()
         return
     g9()
     g10()
     g8b()
+    g12()
 
     # ---- G1 spiral -------------------------------------------------------------------------------------
     g1 = {}
