@@ -12,7 +12,8 @@
 //     registers (packed f32x2 -> v_pk_mul/v_pk_fma): per (b,d,l) element that is N exp2 + ~2.5N packed
 //     VALU ops, i.e. the work-optimal count -- a wave-parallel associative (Blelloch) scan of the same
 //     recurrence costs ~2.5x the VALU work and is ALU-bound below the HBM roof.  Measured (round 2 PMC):
-//     71 VALU instructions per wave-step in the fp32 loop against 67 the mathematics needs, pipe 81 % busy at 1.69 GHz.
+//     71 VALU instructions per wave-step in the fp32 loop against 67 the mathematics needs, pipe 81 % busy at 1.69 GHz
+//     (round 3: the 15 further EXECUTED instructions per step were the waterfall loop of the B/C fetch; removed).
 //   * B_l / C_l are shared by all channels of a sequence: the rows of a block of 8 steps are fetched with ONE vector load
 //     per lane, parked as fp32 in a wave-private LDS slab and read back per step as broadcast ds_read_b128 (the scalar-cache
 //     route of the first version cost 32 SALU unpack operations per step for 16-bit B/C).
@@ -106,6 +107,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     const int lane = threadIdx.x;
     const int bc_step = lane >> 3, bc_part = lane & 7;                    // part 0..3 -> B, 4..7 -> C
     const bool bc_isB = bc_part < 4;
+    // The B-lanes and the C-lanes of the wave read different tensors (two descriptors: a 2-trip waterfall loop per block of 8
+    // steps) and every lane group a different ROW: the row offset therefore rides in the per-lane VGPR offset.  (Rounds 1-2 passed
+    // it as the scalar offset, which made the waterfall loop run once per (tensor, row) = 16 trips of 8 VALU instructions per
+    // block -- the 15 instructions per step that round 2's accounting found executed but not in the static loop count, 86.4 vs 71.)
     const rsrc_t r_bc = make_rsrc(bc_isB ? (const void*)((const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg)
                                          : (const void*)((const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg));
     const int sl_bc = (int)(bc_isB ? p.B_sl : p.C_sl) * EBC;
@@ -167,9 +172,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     auto fetch_bc = [&](int l0, float(&v)[PER]) {        // rows l0 .. l0+PF-1 (clamped), this lane's piece
         int l = l0 + bc_step;
         l = (l < L) ? l : L - 1;
-        // NB r_bc differs between the B-lanes and the C-lanes of the wave: the compiler turns the
-        // non-uniform descriptor into a 2-trip waterfall loop; it runs once per 8 steps.
-        bio_ld_vec<TBC, PER>(v, r_bc, vo_bc, l * sl_bc);
+        bio_ld_vec<TBC, PER>(v, r_bc, vo_bc + l * sl_bc, 0);
     };
     auto stash_bc = [&](int b, const float(&v)[PER]) {
 #pragma unroll

@@ -140,7 +140,7 @@ class GraphedTrainStep:
         # `skipped` counts such steps; the host reads it when it logs.  (The EMA line still runs: it blends towards weights that
         # did not move, a 1 - decay step in place -- it cannot be poisoned.)
         self._one = torch.ones((), device=z.device)
-        self.skipped = torch.zeros(1, device=z.device)
+        self.skipped = torch.zeros((), device=z.device)
         with torch.cuda.device(z.device):
             side = torch.cuda.Stream(device=z.device)
             side.wait_stream(torch.cuda.current_stream(z.device))
@@ -179,7 +179,7 @@ class GraphedTrainStep:
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
             loss = self.diffusion.training_losses(self.model, self.sz, self.st, dict(y=self.sy, y2=self.sy2, w=self.sw))["loss"].mean()
         loss.backward()
-        found = torch.zeros(1, device=self.sz.device)
+        found = torch.zeros((), device=self.sz.device)            # 0-dim like GradScaler's (the fused AdamW subtracts it from its 0-dim step counters)
         grads = [p.grad for p in self._gp if p.grad is not None]
         if grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found, self._one)      # inv_scale 1: a pure check
@@ -220,7 +220,7 @@ class GraphedTrainStep:
                 else:
                     p.grad.copy_(g)
                 off += n
-            found = (~torch.isfinite(self.flat).all()).float().reshape(1)     # after the all-reduce: the same on every rank
+            found = (~torch.isfinite(self.flat).all()).float()     # after the all-reduce: the same on every rank
         self._guarded_update(found)
 
     def step(self, z, t, y, y2, w):

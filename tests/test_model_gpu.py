@@ -413,6 +413,39 @@ def test_graphed_train_step(gpu):
     assert losses == losses2
 
 
+def test_graphed_train_step_drops_a_non_finite_step_on_the_device(gpu):
+    """A replayed graph cannot branch on the host: a batch that yields non-finite gradients must leave weights, AdamW moments and
+    the step counter untouched (found_inf computed inside the graph), be counted in `skipped`, and the run must go
+    on with the next batch -- the graphed counterpart of the reference's `continue` (train.py:254-256)."""
+    import copy
+
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.graphed import GraphedTrainStep
+
+    g, sd, net0, inp = _g5(gpu)
+    d = create_diffusion("")
+    B = inp["x"].shape[0]
+    torch.manual_seed(3)
+    net = copy.deepcopy(net0).train()
+    ema = copy.deepcopy(net).requires_grad_(False)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-3, weight_decay=0, fused=True, capturable=True)
+    t = torch.full((B,), 300, device=gpu, dtype=torch.long)
+    gs = GraphedTrainStep(net, ema, opt, d, inp["x"], t, inp["y"], inp["y2"], inp["w"], ema_decay=0.9, warmup=2)
+    gs.step(inp["x"], t, inp["y"], inp["y2"], inp["w"])
+    before = [p.detach().clone() for p in net.parameters()]
+    steps_before = [float(st["step"]) for st in opt.state.values()]
+    bad = inp["x"].clone()
+    bad[0, 0, 0, 0] = float("nan")
+    loss = gs.step(bad, t, inp["y"], inp["y2"], inp["w"])
+    assert not torch.isfinite(loss).all() and float(gs.skipped) == 1.0
+    assert all(torch.equal(a.detach(), b) for a, b in zip(net.parameters(), before))
+    assert [float(st["step"]) for st in opt.state.values()] == steps_before
+    assert all(torch.isfinite(p).all() for p in ema.parameters())
+    loss = gs.step(inp["x"], t, inp["y"], inp["y2"], inp["w"])               # the run continues
+    assert torch.isfinite(loss).all() and float(gs.skipped) == 1.0
+    assert any(not torch.equal(a.detach(), b) for a, b in zip(net.parameters(), before))
+
+
 # ---- baseline scan orders on the same kernels (SURVEY.md 8f-3; tests/golden/g9_baseline_blocks.npz) ------------------------
 def _g9(gpu, tag):
     from diffma_amd.model import DiffMa
