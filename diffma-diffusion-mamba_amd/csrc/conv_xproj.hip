@@ -269,7 +269,13 @@ namespace dm {
 // in the same pass.  dw / db are accumulated in registers over the WHOLE sequence: one partial row per sequence.
 //   wave w owns the output channels [w * dim/8, (w+1) * dim/8) of the product (dim/128 column tiles of 16);
 //   thread t owns channels 2t, 2t+1 of the convolution (32-bit accesses), like K3x.
-template <typename T, typename TW, int W, bool SILU, int D, bool IDX>
+// MERGED (DM_FLAG_DX_MERGED, round 3): the workgroup owns SAMPLE b and walks its ndir gathered sequences one after the other; dx
+// of every direction goes to ONE token-order buffer [batch][seqlen][dim] -- direction 0 stores, the others read-add-store the
+// rows (the thread that wrote a row element is the thread that reads it back: only its own stores have to have retired, and the
+// reload bypasses the CU's L1) -- so the per-direction dx slabs and the 3-slab dm_token_merge pass of the mixer's backward
+// (CrossScan.backward, block/mamba.py:47-57) disappear, and dw / db leave as one partial row per sample.  Rounding: every slab
+// used to be rounded to the I/O dtype before the merge summed them; here the running sum is rounded instead, the same count.
+template <typename T, typename TW, int W, bool SILU, int D, bool IDX, bool MERGED = false>
 __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_conv_xproj_bwd_args p) {
     constexpr int NTW = D / 128;                                      // column tiles (16 channels) per wave
     constexpr int ROWP = D + 4;                                       // fp32 LDS row stride: rows 4g + r of a D-fragment fall on disjoint banks
@@ -280,18 +286,12 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = lane >> 4, ij = lane & 15;
-    const int s = blockIdx.x;
-    const int dir = s / p.batch;
-    const int b = s - dir * p.batch;
     const int L = p.seqlen;
-    const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;
+    const int b = MERGED ? (int)blockIdx.x : (int)blockIdx.x % p.batch;
     const bool act = (D == 2 * XP_THREADS) ? true : (2 * tid < D);
     const int c = act ? 2 * tid : 0;
     constexpr int ES = (int)sizeof(T);
     const rsrc_t r_x = make_rsrc((const T*)p.x + (int64_t)b * p.x_sb);
-    const rsrc_t r_du = make_rsrc((const T*)p.du + (int64_t)s * p.du_ss);
-    const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)s * p.dx_ss);
-    const rsrc_t r_xd = make_rsrc((const T*)p.dxdbl + (int64_t)s * L * p.xd_sr);
     const rsrc_t r_wt = make_rsrc(p.wxt);                             // [dim][64]
     const int vo = c * ES;
     const int sl_x = (int)p.x_sl * ES, sl_du = (int)p.du_sl * ES, sl_dx = (int)p.dx_sl * ES, sr_xd = (int)p.xd_sr * ES;
@@ -324,8 +324,25 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
     }
 
     const int ntile = (L + XP_TM - 1) / XP_TM;
-    // x rows l0-(W-1) .. l0+15 of a tile (xr[0 .. W-2] = halo); rows before the sequence start are masked at use
     constexpr int NXR = XP_TM + W - 1;
+    const int dir0 = MERGED ? 0 : (int)blockIdx.x / p.batch, dir1 = MERGED ? p.ndir : dir0 + 1;
+#pragma unroll 1
+    for (int dir = dir0; dir < dir1; ++dir) {
+    const int s = dir * p.batch + b;
+    const bool accum = MERGED && dir > 0;                              // read-add-store into the running token-order sum
+    const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;
+    const rsrc_t r_du = make_rsrc((const T*)p.du + (int64_t)s * p.du_ss);
+    const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)(MERGED ? b : s) * p.dx_ss);
+    const rsrc_t r_xd = make_rsrc((const T*)p.dxdbl + (int64_t)s * L * p.xd_sr);
+    if (MERGED) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+#pragma unroll
+            for (int j = 0; j < W - 1; ++j) gwin[j][v] = 0.0f;         // a new sequence: no later rows yet
+        }
+        if (accum) __builtin_amdgcn_s_waitcnt(0);                       // this thread's stores of the previous direction have retired
+    }
+    // x rows l0-(W-1) .. l0+15 of a tile (xr[0 .. W-2] = halo); rows before the sequence start are masked at use
     auto load_x = [&](int l0, uint32_t(&xr)[NXR]) {
 #pragma unroll
         for (int j = 0; j < NXR; ++j) {
@@ -353,12 +370,29 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
             af[kk] = (lr < L) ? (xp_u32x4){q[0], q[1], q[2], q[3]} : (xp_u32x4){0u, 0u, 0u, 0u};
         }
     };
+    // the running sum's rows of a half tile (MERGED, directions after the first), requested with the du rows half a tile ahead;
+    // sc1: the reload must not be served from a line this CU cached during the previous direction's pass
+    uint32_t dold[MERGED ? XP_TM : 1];
+    auto load_old_half = [&](int l0, int h, uint32_t(&o)[MERGED ? XP_TM : 1]) {
+        if constexpr (MERGED) {
+#pragma unroll
+            for (int j = h * (XP_TM / 2); j < (h + 1) * (XP_TM / 2); ++j) {
+                int l = l0 + j;
+                l = l < L ? l : L - 1;
+                o[j] = __builtin_amdgcn_raw_buffer_load_b32(r_dx, vo, (IDX ? idx[l] : l) * sl_dx, 16);
+            }
+        }
+    };
     uint32_t xr[NXR], xn[NXR], dur[XP_TM];
     xp_u32x4 afrag[2], anext[2];
     load_a((ntile - 1) * XP_TM, afrag);
     load_x((ntile - 1) * XP_TM, xr);
     load_du_half((ntile - 1) * XP_TM, 0, dur);
     load_du_half((ntile - 1) * XP_TM, 1, dur);
+    if (MERGED && accum) {
+        load_old_half((ntile - 1) * XP_TM, 0, dold);
+        load_old_half((ntile - 1) * XP_TM, 1, dold);
+    }
 
     for (int t = ntile - 1; t >= 0; --t) {
         const int l0 = t * XP_TM;
@@ -414,10 +448,19 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
                 }
                 if (valid && act) {
                     const int r = IDX ? idx[l] : l;
+                    if (MERGED && accum) {
+                        float o0, o1;
+                        xp_mfma<T>::unpack(dold[j], o0, o1);
+                        dxv[0] += o0;
+                        dxv[1] += o1;
+                    }
                     __builtin_amdgcn_raw_buffer_store_b32(xp_mfma<T>::pack(dxv[0], dxv[1]), r_dx, vo, r * sl_dx, 0);
                 }
             }
-            if (t > 0) load_du_half(l0 - XP_TM, h, dur);
+            if (t > 0) {
+                load_du_half(l0 - XP_TM, h, dur);
+                if (MERGED && accum) load_old_half(l0 - XP_TM, h, dold);
+            }
         }
         __syncthreads();                                               // ptile is rewritten by the next tile's product
 #pragma unroll
@@ -425,7 +468,9 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
         afrag[0] = anext[0];
         afrag[1] = anext[1];
     }
+    }   // directions
     if (act) {
+        const int s = MERGED ? b : (int)blockIdx.x;                   // one partial row per sample (MERGED) or per sequence
         float* dwp = p.dw_partial + ((int64_t)s * D + c) * W;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
@@ -440,6 +485,12 @@ template <typename T, typename TW, int W, int D>
 static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
     dim3 grid(a.ndir * a.batch), block(XP_THREADS);
     const bool silu = (a.flags & DM_FLAG_SILU) != 0;
+    if constexpr (W == 4) {                                          // the merged form is built for the mixer's call pattern
+        if ((a.flags & DM_FLAG_DX_MERGED) && silu && a.row_index) {
+            hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, true, true>), dim3(a.batch), block, 0, st, a);
+            return;
+        }
+    }
     if (a.row_index) {
         if (silu) hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, false, D, true>), grid, block, 0, st, a);
@@ -491,6 +542,9 @@ extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, vo
     if (!a.x || !a.weight || !a.du || !a.dxdbl || !a.wxt || !a.dx || !a.dw_partial) { set_error("dm_gather_conv1d_xproj_bwd: null tensor pointer"); return DM_ERR_ARG; }
     if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_xproj_bwd: non-positive size"); return DM_ERR_ARG; }
     if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_xproj_bwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
+    if ((a.flags & DM_FLAG_DX_MERGED) && !(a.width == 4 && (a.flags & DM_FLAG_SILU) && a.row_index)) {
+        set_error("dm_gather_conv1d_xproj_bwd: DM_FLAG_DX_MERGED is built for width 4, SiLU, row-index tables"); return DM_ERR_ARG;
+    }
     if (!dm_gather_conv1d_xproj_bwd_supported(a.dim, a.nproj, a.io_dtype)) {
         set_error("dm_gather_conv1d_xproj_bwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj = 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
         return DM_ERR_ARG;

@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -413,10 +413,16 @@ def conv_xproj_bwd_supported(x, wx, nseq):
     return bool(_lib.load().dm_gather_conv1d_xproj_bwd_supported(int(x.shape[-1]), int(wx.shape[0]), dtype_code(x)))
 
 
-def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, ndir=1, silu=True):
+# DIFFMA_DX_MERGED=0: per-direction dx slabs + dm_token_merge again (A/B runs)
+DX_MERGED = os.environ.get("DIFFMA_DX_MERGED", "1") == "1"
+
+
+def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, ndir=1, silu=True, merged_out=None):
     """Conv backward whose incoming gradient is du + dxdbl @ wx, formed tile by tile inside the kernel (never materialised).
     x: [B, L, Dm] view; du: [ndir*B, L, Dm]; dxdbl: [ndir*B*L, P] (row stride any multiple of 8); wxt: [Dm, P] = x_proj.weight^T.
-    Returns (dx_slabs [ndir*B, L, Dm] in token order, dweight [Dm, W] fp32, dbias [Dm] fp32)."""
+    Returns (dx_slabs [ndir*B, L, Dm] in token order, dweight [Dm, W] fp32, dbias [Dm] fp32).
+    merged_out: a [B, L, Dm] view that receives the SUM of the directions' dx (DM_FLAG_DX_MERGED: a workgroup walks the directions
+    of a sample, the first stores, the others read-add-store) -- returned in place of the slabs; no token_merge needed."""
     _require_gpu(x, weight, bias, du, dxdbl, wxt)
     Bsz, L, Dm = x.shape
     W = weight.shape[-1]
@@ -431,13 +437,18 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
     assert dxdbl.stride(1) == 1 and du.stride(2) == 1
     S = ndir * Bsz
     dev = x.device
-    dx = torch.empty((S, L, Dm), dtype=x.dtype, device=dev)
-    dw = torch.empty((S, Dm, W), dtype=torch.float32, device=dev)
-    db = torch.empty((S, Dm), dtype=torch.float32, device=dev)
+    merged = merged_out is not None
+    if merged:
+        assert merged_out.shape == (Bsz, L, Dm) and merged_out.dtype == x.dtype and merged_out.stride(2) == 1 and W == 4 and silu and row_index is not None
+        dx, rows = merged_out, Bsz
+    else:
+        dx, rows = torch.empty((S, L, Dm), dtype=x.dtype, device=dev), S
+    dw = torch.empty((rows, Dm, W), dtype=torch.float32, device=dev)
+    db = torch.empty((rows, Dm), dtype=torch.float32, device=dev)
     a = dm_conv_xproj_bwd_args()
     a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
     a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
-    a.flags = DM_FLAG_SILU if silu else 0
+    a.flags = (DM_FLAG_SILU if silu else 0) | (DM_FLAG_DX_MERGED if merged else 0)
     a.nproj = P
     a.x, a.weight, a.bias, a.row_index = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index)
     a.du, a.dxdbl, a.wxt = _ptr(du), _ptr(dxdbl), _ptr(wxt)
@@ -447,8 +458,11 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
     a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
     a.xd_sr = dxdbl.stride(0)
     es = x.element_size()
-    _launch("dm_gather_conv1d_xproj_bwd", a, x, 3 * S * L * Dm * es + S * L * P * es + P * Dm * es)
-    return dx, colsum(dw.view(S, Dm * W)).view(Dm, W), colsum(db)
+    # algorithmic bytes: x and du read per direction, dx written per direction (merged: written once -- the re-reads of the running
+    # sum are design traffic, mostly served by L2 / the Infinity Cache)
+    nbytes = (2 * S + (Bsz if merged else S)) * L * Dm * es + S * L * P * es + P * Dm * es
+    _launch("dm_gather_conv1d_xproj_bwd", a, x, nbytes, nbytes + (2 * (S - Bsz) * L * Dm * es if merged else 0))
+    return dx, colsum(dw.view(rows, Dm * W)).view(Dm, W), colsum(db)
 
 
 def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=True):

@@ -326,14 +326,18 @@ class _SpiralSSMFn(torch.autograd.Function):
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz):
             # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]
+            merged_dx = hip_ops.DX_MERGED and ndir > 1 and conv_w.shape[-1] == 4
             dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_xproj_bwd(xz[..., :Din], conv_w, conv_b, du, dx_dbl, Wx_c.t().contiguous(),
-                                                                         row_index=scan_index, ndir=ndir, silu=True)
+                                                                         row_index=scan_index, ndir=ndir, silu=True,
+                                                                         merged_out=dxz[..., :Din] if merged_dx else None)
         else:
+            merged_dx = False
             # in place: an out-of-place addmm first copies `du` into its result (a 2 x 308 MB device memcpy per call)
             dxc = GemmChain.run(du.view(M, Din).addmm_, dx_dbl, Wx_c).view(ndir * Bsz, L, Din)
             dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_bwd(xz[..., :Din], conv_w, conv_b, dxc,
                                                                    row_index=scan_index, ndir=ndir, silu=True)
-        hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
+        if not merged_dx:                                          # K4x already summed the directions into dxz[..., :Din]
+            hip_ops.token_merge(dx_slabs.view(ndir, Bsz, L, Din), out=dxz[..., :Din])
         if not ctx.hoist:
             hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
         return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 18
+#define DM_ABI_VERSION 19
 
 typedef enum {
     DM_OK = 0,
@@ -61,6 +61,11 @@ enum {
                                    separate merge pass disappears.  One direction per launch (batch_per_dir = 0 or nseq),
                                    d_state 16, z, both index tables, DM_FLAG_DELTA_SOFTPLUS, no DM_FLAG_A_SHARED; the
                                    sequential kernel is taken whatever the launch size.                                   */
+    DM_FLAG_DX_MERGED = 256,    /* dm_gather_conv1d_xproj_bwd: dx is ONE token-order buffer [batch][seqlen][dim] (dx_ss = its batch stride)
+                                   that receives the sum over the ndir directions -- a workgroup walks the directions of a sample one
+                                   after the other, direction 0 stores, the others read-add-store -- instead of ndir slabs for
+                                   dm_token_merge to add; dw_partial / db_partial are then [batch][...] (one row per sample).
+                                   Width 4, SiLU and row-index tables (the mixer's call pattern).                              */
     DM_FLAG_DELTA_ACTIVATED = 128 /* scan fwd / bwd: `delta` already holds softplus(raw + delta_bias) -- the producer applied it
                                    once per element (dm_dtproj_softplus_fwd) instead of every scan direction evaluating it in
                                    the forward AND in the backward.  Forward: delta is used as is, delta_bias is ignored.

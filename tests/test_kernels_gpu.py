@@ -950,3 +950,46 @@ def test_spiral_ssm_hoisted_equals_in_scan_gate(gpu, dtype, monkeypatch):
     for name, p, q in zip(["y", "dxz", "dconv_w", "dconv_b", "dWx", "dWdt", "ddt_bias", "dA", "dD"], a, b):
         sc = max(1.0, float(q.abs().max()))
         torch.testing.assert_close(p, q, rtol=tol["rtol"], atol=tol["atol"] * sc, msg=lambda m, name=name: f"{name}: {m}")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Bsz,L,Dm,ndir", [(2, 196, 1024, 3), (3, 49, 128, 3), (2, 5, 1024, 2), (1, 37, 128, 4)])
+def test_fused_conv_xproj_bwd_merged_directions(gpu, dtype, Bsz, L, Dm, ndir):
+    """K4x with DM_FLAG_DX_MERGED: one workgroup per sample walks the directions, dx accumulates in ONE token-order buffer (a strided
+    view: the x half of d(xz)); against fp64 autograd (the gradient of x summed over the directions), against the slab form +
+    dm_token_merge, and dw / db from one partial row per sample.  The neighbouring z half must stay untouched."""
+    from diffma_amd import hip_ops
+    from oracle.mamba_ref import causal_conv1d_ref
+
+    P, W = 64, 4
+    g = torch.Generator().manual_seed(L * 7 + Dm + ndir)
+    xz = torch.randn(Bsz, L, 2 * Dm, generator=g).to(dtype)
+    w = torch.randn(Dm, W, generator=g) * 0.5
+    b = torch.randn(Dm, generator=g) * 0.1
+    wx = (torch.randn(P, Dm, generator=g) * 0.1).to(dtype)
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int()
+    du = torch.randn(ndir * Bsz, L, Dm, generator=g).to(dtype)
+    dxdbl = torch.randn(ndir * Bsz * L, P, generator=g).to(dtype)
+    dxz = torch.full((Bsz, L, 2 * Dm), 7.0, dtype=dtype, device=gpu)
+    args = (xz.to(gpu)[..., :Dm], w.to(gpu), b.to(gpu), du.to(gpu), dxdbl.to(gpu), wx.to(gpu).t().contiguous())
+    dx, dw, db = hip_ops.gather_conv1d_xproj_bwd(*args, row_index=perms.to(gpu), ndir=ndir, merged_out=dxz[..., :Dm])
+    slabs, dw2, db2 = hip_ops.gather_conv1d_xproj_bwd(*args, row_index=perms.to(gpu), ndir=ndir)
+    torch.cuda.synchronize()
+    assert dx.data_ptr() == dxz.data_ptr() and float((dxz[..., Dm:] - 7.0).abs().max()) == 0.0
+    x = xz[..., :Dm].float().double().clone().requires_grad_(True)
+    wd, bd = w.double().clone().requires_grad_(True), b.double().clone().requires_grad_(True)
+    loss = 0
+    for k in range(ndir):
+        y = causal_conv1d_ref(x[:, perms[k].long(), :].permute(0, 2, 1), wd, bd, activation="silu").permute(0, 2, 1)
+        loss = loss + (y * du.view(ndir, Bsz, L, Dm)[k].float().double()).sum() \
+            + ((y.reshape(-1, Dm) @ wx.float().double().t()) * dxdbl.view(ndir, Bsz * L, P)[k].float().double()).sum()
+    loss.backward()
+    rtol, atol = {torch.bfloat16: (3e-2, 5e-2), torch.float16: (4e-3, 8e-3)}[dtype]
+    sc = max(1.0, x.grad.abs().max().item())
+    torch.testing.assert_close(dxz[..., :Dm].float().cpu().double(), x.grad, rtol=rtol, atol=atol * sc)
+    merged = hip_ops.token_merge(slabs.view(ndir, Bsz, L, Dm)).float().cpu()
+    torch.testing.assert_close(dxz[..., :Dm].float().cpu(), merged, rtol=rtol, atol=atol * sc)
+    sc = max(1.0, wd.grad.abs().max().item())
+    torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=rtol, atol=atol * sc * 0.2)
+    torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=rtol, atol=atol * sc * 0.2)
+    torch.testing.assert_close(dw.cpu(), dw2.cpu(), rtol=1e-4, atol=1e-4 * sc)

@@ -9,7 +9,7 @@ python - <<PY
 import sqlite3, glob
 db = glob.glob("$OUT/trace/*.db")[0]
 cur = sqlite3.connect(db).cursor()
-rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 45"))
+rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 80"))
 tot = sum(r[2] for r in cur.execute("select name, total_calls, total_duration from top_kernels"))
 with open("$OUT/top.txt", "w") as f:
     f.write(f"total kernel time (4 steps incl. warmup): {tot/1e3:.1f} us-units\n")
