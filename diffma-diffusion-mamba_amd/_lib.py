@@ -93,6 +93,7 @@ dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 dm_colsum_args = _make_struct("dm_colsum_args")
+dm_sum_partials_args = _make_struct("dm_sum_partials_args")
 dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
 dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
 dm_ssd_bwd_args = _make_struct("dm_ssd_bwd_args")

@@ -471,12 +471,12 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
     }   // directions
     if (act) {
         const int s = MERGED ? b : (int)blockIdx.x;                   // one partial row per sample (MERGED) or per sequence
-        float* dwp = p.dw_partial + ((int64_t)s * D + c) * W;
+        float* dwp = p.dw_partial + (int64_t)s * (p.part_ss ? p.part_ss : (int64_t)D * W) + (int64_t)c * W;
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
 #pragma unroll
             for (int k = 0; k < W; ++k) dwp[v * W + k] = dw[k][v];
-            if (p.db_partial) p.db_partial[(int64_t)s * D + c + v] = db[v];
+            if (p.db_partial) p.db_partial[(int64_t)s * (p.part_ss ? p.part_ss : (int64_t)D) + c + v] = db[v];
         }
     }
 }

@@ -244,3 +244,49 @@ extern "C" int dm_colsum_f32(const dm_colsum_args* args, void* stream) {
     if (e != hipSuccess) { set_error("dm_colsum_f32: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// dm_sum_partials -- out[m][c] = sum_w in[m][w][c], converted and placed with a row stride (see include/diffma_hip.h).
+// One thread per 4 output columns; the nw partial rows of an output row are 16-B loads nw*cols floats apart.
+// ------------------------------------------------------------------------------------------------------------
+namespace dm {
+template <typename TO>
+__global__ __launch_bounds__(256) void sum_partials_kernel(const dm_sum_partials_args p) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (row, 4-column group)
+    const int cg = p.cols / 4;
+    if (q >= p.rows * cg) return;
+    const int64_t m = q / cg;
+    const int c = (int)(q - m * cg) * 4;
+    const float* src = p.in + (m * p.nw) * p.cols + c;
+    f32x4 acc = *reinterpret_cast<const f32x4*>(src);
+    for (int w = 1; w < p.nw; ++w) acc += *reinterpret_cast<const f32x4*>(src + (int64_t)w * p.cols);
+    TO* dst = (TO*)p.out + m * p.out_sr + c;
+    alignas(8) TO o[4];
+    io<TO>::st(&o[0], acc.x); io<TO>::st(&o[1], acc.y); io<TO>::st(&o[2], acc.z); io<TO>::st(&o[3], acc.w);
+    if constexpr (sizeof(TO) == 2) *reinterpret_cast<f32x2*>(dst) = *reinterpret_cast<const f32x2*>(o);
+    else *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(o);
+}
+}  // namespace dm
+
+extern "C" int dm_sum_partials(const dm_sum_partials_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_sum_partials: null args"); return DM_ERR_ARG; }
+    const dm_sum_partials_args& a = *args;
+    if (!a.in || !a.out) { set_error("dm_sum_partials: null tensor pointer"); return DM_ERR_ARG; }
+    if (a.rows <= 0 || a.nw <= 0 || a.cols <= 0 || a.cols % 4 != 0) { set_error("dm_sum_partials: rows, nw, cols must be positive and cols a multiple of 4"); return DM_ERR_ARG; }
+    const int es = a.out_dtype == DM_F32 ? 4 : 2;
+    if (((uintptr_t)a.in % 16) || ((uintptr_t)a.out % (4 * es)) || (a.out_sr % 4)) { set_error("dm_sum_partials: in must be 16-byte aligned, out rows aligned to 4 elements"); return DM_ERR_LAYOUT; }
+    const int64_t n = a.rows * (a.cols / 4);
+    if ((n + 255) / 256 > 0x7fffffff) { set_error("dm_sum_partials: too many rows"); return DM_ERR_ARG; }
+    dim3 grid((unsigned)((n + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.out_dtype) {
+        case DM_F32: hipLaunchKernelGGL((sum_partials_kernel<float>), grid, dim3(256), 0, st, a); break;
+        case DM_BF16: hipLaunchKernelGGL((sum_partials_kernel<bf16_t>), grid, dim3(256), 0, st, a); break;
+        case DM_F16: hipLaunchKernelGGL((sum_partials_kernel<f16_t>), grid, dim3(256), 0, st, a); break;
+        default: set_error("dm_sum_partials: bad out_dtype %d", a.out_dtype); return DM_ERR_DTYPE;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_sum_partials: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}

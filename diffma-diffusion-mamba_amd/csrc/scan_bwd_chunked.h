@@ -357,15 +357,16 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
     xch_lds[c][0][N + 1][lane] = dbias_acc;
     __syncthreads();
     if (c == 0 && active) {
-        float* dAp = p.dA_partial + ((int64_t)s * p.dim + d) * N;
+        const int64_t pss_a = p.part_ss ? p.part_ss : (int64_t)p.dim * N, pss_d = p.part_ss ? p.part_ss : (int64_t)p.dim;
+        float* dAp = p.dA_partial + (int64_t)s * pss_a + (int64_t)d * N;
 #pragma unroll
         for (int n = 0; n < N + 2; ++n) {
             float acc = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) acc += xch_lds[w][0][n][lane];
             if (n < N) dAp[n] = acc;
-            else if (n == N) { if (p.dD_partial) p.dD_partial[(int64_t)s * p.dim + d] = acc; }
-            else { if (p.dbias_partial) p.dbias_partial[(int64_t)s * p.dim + d] = acc; }
+            else if (n == N) { if (p.dD_partial) p.dD_partial[(int64_t)s * pss_d + d] = acc; }
+            else { if (p.dbias_partial) p.dbias_partial[(int64_t)s * pss_d + d] = acc; }
         }
     }
 }

@@ -537,15 +537,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         buf ^= 1;
     }
     if (active) {
-        float* dAp = p.dA_partial + ((int64_t)s * p.dim + d) * N + q * NS;
+        const int64_t pss_a = p.part_ss ? p.part_ss : (int64_t)p.dim * N, pss_d = p.part_ss ? p.part_ss : (int64_t)p.dim;
+        float* dAp = p.dA_partial + (int64_t)s * pss_a + (int64_t)d * N + q * NS;
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             dAp[2 * k] = dA[k].x;
             dAp[2 * k + 1] = dA[k].y;
         }
         if (q == 0) {
-            if (p.dD_partial) p.dD_partial[(int64_t)s * p.dim + d] = dD_acc;
-            if (p.dbias_partial) p.dbias_partial[(int64_t)s * p.dim + d] = dbias_acc;
+            if (p.dD_partial) p.dD_partial[(int64_t)s * pss_d + d] = dD_acc;
+            if (p.dbias_partial) p.dbias_partial[(int64_t)s * pss_d + d] = dbias_acc;
         }
     }
 }

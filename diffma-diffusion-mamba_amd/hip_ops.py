@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -253,10 +253,15 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     if z is not None:
         dz = dz_out if dz_out is not None else torch.empty((S, L, Dm), dtype=u.dtype, device=dev)
     dBC = torch.empty((S, L, nw, 2 * N), dtype=torch.float32, device=dev)
-    dA = torch.empty((S, Dm, N), dtype=torch.float32, device=dev)
-    dD = torch.empty((S, Dm), dtype=torch.float32, device=dev) if D is not None else None
-    dbias = torch.empty((S, Dm), dtype=torch.float32, device=dev) if (delta_bias is not None or delta_activated) else None
+    # per-sequence partial rows of dA | dD | dbias as column blocks of ONE buffer: one column sum instead of three
+    want_dD, want_db = D is not None, (delta_bias is not None or delta_activated)
+    pcols = Dm * N + Dm * (int(want_dD) + int(want_db))
+    part = torch.empty((S, pcols), dtype=torch.float32, device=dev)
+    dA = part[:, :Dm * N]
+    dD = part[:, Dm * N:Dm * N + Dm] if want_dD else None
+    dbias = part[:, pcols - Dm:] if want_db else None
     a = dm_scan_bwd_args()
+    a.part_ss = pcols
     a.nseq, a.dim, a.seqlen, a.dstate = S, Dm, L, N
     a.ngroups = ngroups
     a.batch_per_dir = batch_per_dir
@@ -287,14 +292,39 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     design = nbytes + 2 * S * N * L * Bm.element_size() + S * L * (nw - 1) * 2 * N * 4 + 4 * S * Dm * (N + 2) \
         + (scan_nchunk(L, ckpt_every) - 1 + (L % ckpt_every == 0)) * S * ckpt.shape[2] * Dm * 4   # slot 0 is read when L ends on a boundary
     _launch("dm_selective_scan_bwd", a, u, nbytes, design)
-    if dbc_out is not None:                     # [S, L, 2N] view (any stride / dtype) in the caller's buffer: fp32 sum, ONE converting copy
-        dbc_out.copy_(dBC.sum(dim=2))           # (sum(..., dtype=bf16, out=) would first cast the whole partial tensor)
-        dBCs = dbc_out
+    if dbc_out is not None:                     # [S, L, 2N] view in the caller's buffer (the dB | dC columns of d x_dbl): summed + placed in one pass
+        dBCs = sum_partials(dBC.view(S * L, nw, 2 * N), dbc_out)
     else:
-        dBCs = dBC.sum(dim=2)                   # [S, L, 2N] fp32, deterministic
+        dBCs = sum_partials(dBC.view(S * L, nw, 2 * N), torch.empty((S, L, 2 * N), dtype=torch.float32, device=dev))   # deterministic
     dB, dC = dBCs[..., :N], dBCs[..., N:]
-    return (du, ddelta, dz, dB, dC, colsum(dA.view(S, Dm * N)).view(Dm, N), colsum(dD) if dD is not None else None,
-            colsum(dbias) if dbias is not None else None)
+    psum = colsum(part)                         # [Dm*N | Dm | Dm]
+    return (du, ddelta, dz, dB, dC, psum[:Dm * N].view(Dm, N), psum[Dm * N:Dm * N + Dm] if want_dD else None,
+            psum[pcols - Dm:] if want_db else None)
+
+
+def sum_partials(parts, out):
+    """parts [M, nw, C] fp32 contiguous -> out[..., :C] = parts.sum(1), converted to out's dtype; out is any [.., C] tensor / view whose
+    leading dims flatten to M rows of one stride (e.g. the dB | dC columns of the d x_dbl buffer).  Returns out."""
+    M, nw, C = parts.shape
+    o2 = out.reshape(M, C) if out.is_contiguous() else None
+    if o2 is None:                              # a column block of a wider row-major buffer: rows must be evenly strided
+        st = out.stride()
+        sr = st[-2]
+        ok = out.stride(-1) == 1 and all(st[i] == st[i + 1] * out.shape[i + 1] for i in range(out.dim() - 2))
+        o2 = out.as_strided((M, C), (sr, 1)) if ok else None
+    es = out.element_size()
+    if (o2 is None or C % 4 or not parts.is_contiguous() or parts.dtype != torch.float32 or out.dtype not in _DT
+            or o2.data_ptr() % (4 * es) or o2.stride(0) % 4):
+        out.copy_(parts.sum(dim=1).view(out.shape))
+        return out
+    a = dm_sum_partials_args()
+    a.rows, a.nw, a.cols = M, nw, C
+    a.out_dtype = _DT[out.dtype]
+    setattr(a, "in", _ptr(parts))
+    a.out = _ptr(o2)
+    a.out_sr = o2.stride(0)
+    _launch("dm_sum_partials", a, parts, M * C * (nw * 4 + es))
+    return out
 
 
 _COLSUM_SMALL = os.environ.get("DIFFMA_COLSUM_SMALL", "1") == "1"
@@ -443,9 +473,10 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
         dx, rows = merged_out, Bsz
     else:
         dx, rows = torch.empty((S, L, Dm), dtype=x.dtype, device=dev), S
-    dw = torch.empty((rows, Dm, W), dtype=torch.float32, device=dev)
-    db = torch.empty((rows, Dm), dtype=torch.float32, device=dev)
+    part = torch.empty((rows, Dm * (W + 1)), dtype=torch.float32, device=dev)     # dw | db partial rows in one buffer: one column sum
+    dw, db = part[:, :Dm * W], part[:, Dm * W:]
     a = dm_conv_xproj_bwd_args()
+    a.part_ss = Dm * (W + 1)
     a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
     a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
     a.flags = (DM_FLAG_SILU if silu else 0) | (DM_FLAG_DX_MERGED if merged else 0)
@@ -462,7 +493,8 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
     # sum are design traffic, mostly served by L2 / the Infinity Cache)
     nbytes = (2 * S + (Bsz if merged else S)) * L * Dm * es + S * L * P * es + P * Dm * es
     _launch("dm_gather_conv1d_xproj_bwd", a, x, nbytes, nbytes + (2 * (S - Bsz) * L * Dm * es if merged else 0))
-    return dx, colsum(dw.view(rows, Dm * W)).view(Dm, W), colsum(db)
+    psum = colsum(part)
+    return dx, psum[:Dm * W].view(Dm, W), psum[Dm * W:]
 
 
 def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=True):

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 19
+#define DM_ABI_VERSION 20
 
 typedef enum {
     DM_OK = 0,
@@ -168,6 +168,9 @@ typedef struct {
     int64_t du_ss, du_sl, du_sd;
     int64_t ddt_ss, ddt_sl, ddt_sd;
     int64_t dz_ss, dz_sl, dz_sd;
+    int64_t part_ss;         /* row (per-sequence) stride in floats of dA_partial / dD_partial / dbias_partial; 0 = packed
+                                (dim*dstate, dim, dim).  With one stride the three can be column blocks of ONE
+                                [nseq][dim*(dstate+2)] buffer that a single dm_colsum_f32 reduces.                        */
 } dm_scan_bwd_args;
 
 int dm_selective_scan_bwd(const dm_scan_bwd_args *args, void *stream);
@@ -277,6 +280,7 @@ typedef struct {
     int64_t du_ss, du_sl, du_sd;
     int64_t dx_ss, dx_sl, dx_sd;
     int64_t xd_sr;
+    int64_t part_ss;          /* row stride in floats of dw_partial / db_partial; 0 = packed (dim*width, dim) */
 } dm_conv_xproj_bwd_args;
 
 int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args *args, void *stream);
@@ -438,6 +442,20 @@ typedef struct {
 } dm_colsum_args;
 
 int dm_colsum_f32(const dm_colsum_args *args, void *stream);
+
+/* out[m][c] = sum_w in[m][w][c] : the per-workgroup dB/dC partial rows of dm_selective_scan_bwd ([rows][nw][cols] fp32,
+ * contiguous) summed and placed -- converted to out_dtype -- into their columns of the d x_dbl buffer (row stride out_sr
+ * elements) in one pass (ATen: a reduction into a temporary + a converting strided copy). */
+typedef struct {
+    int64_t rows;
+    int32_t nw, cols;
+    int32_t out_dtype, _pad;
+    const float *in;
+    void *out;
+    int64_t out_sr;
+} dm_sum_partials_args;
+
+int dm_sum_partials(const dm_sum_partials_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Mamba-2 SSD core, single chunk, on the matrix pipe (forward of --use-mamba2 with 16-bit activations).  Replaces the scan stage of

@@ -993,3 +993,21 @@ def test_fused_conv_xproj_bwd_merged_directions(gpu, dtype, Bsz, L, Dm, ndir):
     torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=rtol, atol=atol * sc * 0.2)
     torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=rtol, atol=atol * sc * 0.2)
     torch.testing.assert_close(dw.cpu(), dw2.cpu(), rtol=1e-4, atol=1e-4 * sc)
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,nw,C", [(2 * 196, 4, 32), (37, 1, 32), (5, 16, 64)])
+def test_sum_partials_matches_torch(gpu, out_dtype, M, nw, C):
+    """dB/dC partial rows summed and placed into a column block of a wider buffer (the d x_dbl columns) in one pass."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(M + nw)
+    parts = torch.randn(M, nw, C, generator=g).to(gpu)
+    wide = torch.full((M, 32 + C), 3.0, dtype=out_dtype, device=gpu)
+    hip_ops.sum_partials(parts, wide[:, 32:])
+    ref = parts.sum(1).to(out_dtype)
+    tol = dict(rtol=1e-6, atol=1e-6) if out_dtype == torch.float32 else dict(rtol=8e-3, atol=1e-2)
+    torch.testing.assert_close(wide[:, 32:], ref, **tol)
+    assert float((wide[:, :32] - 3.0).abs().max()) == 0.0
+    out3 = torch.empty(M // 1, C, dtype=out_dtype, device=gpu)
+    torch.testing.assert_close(hip_ops.sum_partials(parts, out3), ref, **tol)
