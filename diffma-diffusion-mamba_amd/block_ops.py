@@ -17,45 +17,78 @@ def _autocast_dtype(x):
     return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
 
 
+# PASS-THROUGH outputs.  x (and x2) of the two LayerNorm nodes of a block have a SECOND consumer -- the residual / the blend -- so
+# autograd would add the two gradient contributions with one elementwise pass per tensor (3 per block: 48 launches, 3.1 ms per
+# DiffMa-L/2 step at batch 512).  With passthrough=True the node also returns x (x2) itself; the caller hands THAT alias to the
+# other consumer, the input then has one consumer only, and this node's backward receives the other consumer's gradient and lets
+# dm_ln_mod_bwd add it (one extra read inside a pass that runs anyway).  Two forms: the blend's gradients of x_ssm / w_ssm are
+# fresh tensors of its own backward and are accumulated IN PLACE; the residual's gradient is the block output's gradient itself
+# -- autograd may share that tensor with other nodes (an AddBackward of a long skip hands ONE tensor to both operands) -- so it
+# is only READ (dx_add) and the sum goes to a new tensor.
+PASSTHROUGH = __import__("os").environ.get("DIFFMA_LN_PASSTHROUGH", "1") == "1"
+
+
 class _LnModFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
-        x = x.contiguous()
+    def forward(ctx, x, x2, gamma, beta, shift, scale, mask, eps, y_dtype, passthrough=False):
+        xc = x.contiguous()
         x2c = x2.contiguous() if x2 is not None else None
-        y1, y2, stats = hip_ops.ln_mod_fwd(x, x2c, gamma, beta, shift, scale, mask, eps, y_dtype)
+        y1, y2, stats = hip_ops.ln_mod_fwd(xc, x2c, gamma, beta, shift, scale, mask, eps, y_dtype)
         ctx.eps = eps
         ctx.has = (x2 is not None, gamma is not None, beta is not None, scale is not None, mask is not None)
-        ctx.save_for_backward(x, x2c, gamma, beta, shift, scale, mask, stats)
-        if mask is not None:
-            return y1, y2
-        return y1
+        ctx.passthrough = passthrough
+        ctx.save_for_backward(xc, x2c, gamma, beta, shift, scale, mask, stats)
+        outs = (y1, y2) if mask is not None else (y1,)
+        if passthrough:
+            outs = outs + ((x, x2) if x2 is not None else (x,))
+        return outs if len(outs) > 1 else outs[0]
 
     @staticmethod
-    def backward(ctx, dy1, dy2=None):
+    def backward(ctx, *grads):
         x, x2, gamma, beta, shift, scale, mask, stats = ctx.saved_tensors
         has_x2, has_g, has_b, has_mod, has_mask = ctx.has
+        ny = 2 if has_mask else 1
+        dy1, dy2 = grads[0], (grads[1] if has_mask else None)
+        res = grads[ny:] if ctx.passthrough else ()
         if dy1 is None:
             dy1 = torch.zeros((x.shape[0], x.shape[1], x.shape[2] + (x2.shape[2] if has_x2 else 0)), dtype=dy2.dtype, device=x.device)
         dy1 = dy1.contiguous()
         if dy2 is not None:
             dy2 = dy2.contiguous().to(dy1.dtype)
+        # gradients that arrived through the pass-through aliases
+        rx = res[0] if len(res) > 0 else None
+        rx2 = res[1] if len(res) > 1 else None
+        kw, plain = {}, True
+        if has_x2 and rx is not None and rx2 is not None:               # LN(cat): the blend's own fresh dxs / dws -> in place
+            rx = rx if (rx.is_contiguous() and rx.dtype == x.dtype) else rx.contiguous().to(x.dtype)
+            rx2 = rx2 if (rx2.is_contiguous() and rx2.dtype == x2.dtype) else rx2.contiguous().to(x2.dtype)
+            kw, plain = dict(dx=rx, dx2=rx2, accumulate=True), False
+        elif not has_x2 and rx is not None and rx.dtype == x.dtype and rx.is_contiguous():
+            kw, plain = dict(dx_add=rx), False                          # residual: possibly shared -> read only
         dx, dx2, dshift, dscale, dgamma, dbeta = hip_ops.ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, ctx.eps, stats, dy1,
-                                                                    dy2 if has_mask else None)
+                                                                    dy2 if has_mask else None, **kw)
+        if plain:                                     # odd cases (one alias unused, dtype mismatch): plain sums
+            if rx is not None:
+                dx = dx + rx.to(dx.dtype)
+            if rx2 is not None:
+                dx2 = dx2 + rx2.to(dx2.dtype)
         return (dx, dx2 if has_x2 else None, dgamma.to(gamma.dtype) if has_g else None, dbeta.to(beta.dtype) if has_b else None,
-                dshift.to(shift.dtype) if has_mod else None, dscale.to(scale.dtype) if has_mod else None, None, None, None)
+                dshift.to(shift.dtype) if has_mod else None, dscale.to(scale.dtype) if has_mod else None, None, None, None, None)
 
 
-def ln_modulate_mask(x, norm: torch.nn.LayerNorm, shift, scale, w):
-    """(modulate(LN(x), shift, scale), same * w) with outputs in the autocast dtype.  shift/scale: [B, C] views."""
+def ln_modulate_mask(x, norm: torch.nn.LayerNorm, shift, scale, w, passthrough=False):
+    """(modulate(LN(x), shift, scale), same * w) with outputs in the autocast dtype.  shift/scale: [B, C] views.
+    passthrough: also returns x itself for the residual branch (see PASS-THROUGH above): (x_ssm, w_ssm, x_res)."""
     with torch.autocast(device_type="cuda", enabled=False):
         return _LnModFn.apply(x, None, norm.weight, norm.bias, shift, scale, w.reshape(x.shape[0], x.shape[1]).contiguous().to(shift.dtype),
-                              norm.eps, _autocast_dtype_cached[0])
+                              norm.eps, _autocast_dtype_cached[0], passthrough)
 
 
-def ln_cat(xs, ws, norm: torch.nn.LayerNorm):
-    """LN(cat[xs, ws], dim=-1) without materialising the cat; output in the dtype of xs."""
+def ln_cat(xs, ws, norm: torch.nn.LayerNorm, passthrough=False):
+    """LN(cat[xs, ws], dim=-1) without materialising the cat; output in the dtype of xs.
+    passthrough: (hcat, xs, ws) with the two aliases to be used by the blend."""
     with torch.autocast(device_type="cuda", enabled=False):
-        return _LnModFn.apply(xs, ws, norm.weight, norm.bias, None, None, None, norm.eps, xs.dtype)
+        return _LnModFn.apply(xs, ws, norm.weight, norm.bias, None, None, None, norm.eps, xs.dtype, passthrough)
 
 
 class _BlendFn(torch.autograd.Function):

@@ -184,7 +184,12 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = rstd * (dxh[it][j] - m1 - xh[it][j] * m2);
                 TX* dst = (c < p.C1) ? (TX*)p.dx + r * p.dx_sr + c : (TX*)p.dx2 + r * p.dx2_sr + (c - p.C1);
-                if (p.accumulate) {
+                if (p.dx_add) {                       // read-only second gradient of x (C2 == 0: validated)
+                    float old[VEC];
+                    ld_vec<TX, VEC>(old, (const TX*)p.dx_add + r * p.dxa_sr + c);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] += old[j];
+                } else if (p.accumulate) {
                     float old[VEC];
                     ld_vec<TX, VEC>(old, dst);
 #pragma unroll
@@ -345,7 +350,8 @@ static int ln_launch(const dm_ln_mod_args& a, hipStream_t st, bool bwd) {
                   (!a.gamma || al16(a.gamma)) && (!a.beta || al16(a.beta)) && ok(a.y_sr, ey) &&
                   (!a.scale || (al16(a.scale) && al16(a.shift) && ok(a.mod_sb, (int)sizeof(TM))));
     if (!bwd) vec_ok = vec_ok && al16(a.y1) && (!a.y2 || al16(a.y2));
-    else vec_ok = vec_ok && al16(a.dy1) && (!a.dy2 || al16(a.dy2)) && al16(a.dx) && ok(a.dx_sr, ex) && (!a.dx2 || (al16(a.dx2) && ok(a.dx2_sr, ex)));
+    else vec_ok = vec_ok && al16(a.dy1) && (!a.dy2 || al16(a.dy2)) && al16(a.dx) && ok(a.dx_sr, ex) && (!a.dx2 || (al16(a.dx2) && ok(a.dx2_sr, ex))) &&
+                  (!a.dx_add || (al16(a.dx_add) && ok(a.dxa_sr, ex)));
     const int64_t rows = (int64_t)a.batch * a.rows_per_batch;
     if (!bwd) {
         dim3 grid((unsigned)((rows + LN_WAVES - 1) / LN_WAVES));
@@ -375,6 +381,7 @@ static int ln_entry(const dm_ln_mod_args* args, void* stream, bool bwd) {
     if ((a.scale == nullptr) != (a.shift == nullptr)) { set_error("%s: shift and scale go together", who); return DM_ERR_ARG; }
     if (!bwd && (!a.y1 || (a.mask != nullptr) != (a.y2 != nullptr))) { set_error("%s: y1 required, y2 iff mask", who); return DM_ERR_ARG; }
     if (bwd && (!a.dy1 || !a.dx || !a.stats || !a.part || (a.C2 > 0 && !a.dx2) || (a.dy2 && !a.mask))) { set_error("%s: missing backward buffer", who); return DM_ERR_ARG; }
+    if (bwd && a.dx_add && a.C2 > 0) { set_error("%s: dx_add is for the single-input form (C2 == 0)", who); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (a.x_dtype == DM_F32 && a.y_dtype == DM_F32) rc = ln_by_mod<float, float>(a, st, bwd);

@@ -648,8 +648,9 @@ def ln_mod_fwd(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
     return y1, y2, stats
 
 
-def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=None, dx2=None, accumulate=False):
-    """Returns (dx, dx2, dshift, dscale, dgamma, dbeta); dx/dx2 may be given (accumulate=True adds into them)."""
+def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=None, dx2=None, accumulate=False, dx_add=None):
+    """Returns (dx, dx2, dshift, dscale, dgamma, dbeta); dx/dx2 may be given (accumulate=True adds into them); dx_add [B, L, C1]
+    (x's dtype, read-only): dx = computed + dx_add -- the gradient of x's other consumer, which may be shared and stays intact."""
     _require_gpu(x, dy1)
     a, Bsz, L, C1, C2 = _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, dy1.dtype)
     C = C1 + C2
@@ -663,6 +664,9 @@ def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=
     a.dx_sr = dx.stride(1)
     a.dx2_sr = dx2.stride(1) if dx2 is not None else 0
     a.accumulate = 1 if accumulate else 0
+    if dx_add is not None:
+        assert x2 is None and dx_add.shape == x.shape and dx_add.dtype == x.dtype and dx_add.stride(2) == 1 and dx_add.stride(0) == L * dx_add.stride(1)
+        a.dx_add, a.dxa_sr = _ptr(dx_add), dx_add.stride(1)
     assert dy1.is_contiguous() and (dy2 is None or dy2.is_contiguous())
     _launch("dm_ln_mod_bwd", a, x, Bsz * L * C * (2 * x.element_size() + dy1.element_size() * (2 if dy2 is not None else 1)))
     pb = part.sum(1)                          # [B, 4, C]

@@ -111,11 +111,18 @@ class Spiral_MambaBlock(nn.Module):
         if self.fused_elementwise and x.is_cuda:
             act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
             block_ops.set_output_dtype(act)
-            x_ssm, w_ssm = block_ops.ln_modulate_mask(x, self.norm1, shift, scale, w)
+            pt = block_ops.PASSTHROUGH and torch.is_grad_enabled()
+            if pt:      # x, x_ssm, w_ssm each feed a LayerNorm node AND the blend: the aliases keep them single-consumer (block_ops)
+                x_ssm, w_ssm, x = block_ops.ln_modulate_mask(x, self.norm1, shift, scale, w, passthrough=True)
+            else:
+                x_ssm, w_ssm = block_ops.ln_modulate_mask(x, self.norm1, shift, scale, w)
             x_ssm, w_ssm = self._mixers(x_ssm, w_ssm)
             net = self.attention_network
             # the two Linear layers of the fusion MLP through linear_splitk: their weight gradients reduce over B*L rows
-            hcat = block_ops.ln_cat(x_ssm, w_ssm, net[0])
+            if pt:
+                hcat, x_ssm, w_ssm = block_ops.ln_cat(x_ssm, w_ssm, net[0], passthrough=True)
+            else:
+                hcat = block_ops.ln_cat(x_ssm, w_ssm, net[0])
             a = net[4](linear_splitk(net[2](linear_splitk(hcat, net[1].weight, net[1].bias)), net[3].weight, net[3].bias))
             return block_ops.blend_residual(x, x_ssm, w_ssm, a, gate)
         x_ssm = modulate(self.norm1(x), shift, scale)

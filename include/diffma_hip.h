@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 20
+#define DM_ABI_VERSION 21
 
 typedef enum {
     DM_OK = 0,
@@ -363,7 +363,8 @@ int dm_dtproj_softplus_supported(int dim, int rank, int io_dtype);
  * dm_ln_mod_bwd :  given dy1 (, dy2): dx (, dx2), and fp32 partial sums over groups of DM_LN_ROWS_PER_BLOCK rows
  *                  part[blk][4][C] = {dshift, dscale, dgamma, dbeta}  (blk = b*blocks_per_batch + i);
  *                  accumulate != 0 adds into dx/dx2 instead of overwriting (the cat branch adds to the blend's
- *                  gradients).
+ *                  gradients); dx_add != NULL: dx = (computed) + dx_add[row] read-only (the residual branch's gradient,
+ *                  which may be shared with other autograd nodes and must not be modified), x dtype, row stride dxa_sr.
  * dm_blend_fwd  :  out = x + gate[b] * (a[row]*xs + (1-a[row])*ws)      (:113-114)
  * dm_blend_bwd  :  dxs = g*gate*a, dws = g*gate*(1-a), da[row] = sum_c g*gate*(xs-ws),
  *                  dgate_part[blk][C] = sum_rows g*(a*xs+(1-a)*ws)        (dx = g is the caller's)
@@ -385,6 +386,8 @@ typedef struct {
     void *dx, *dx2;                             /* bwd outputs                                               */
     float *part;                                /* bwd: [batch*blocks_per_batch][4][C]                       */
     int64_t x_sr, x2_sr, y_sr, mod_sb, dx_sr, dx2_sr;
+    const void *dx_add;                         /* bwd only, optional (C2 must be 0)                         */
+    int64_t dxa_sr;
 } dm_ln_mod_args;
 
 int dm_ln_mod_fwd(const dm_ln_mod_args *args, void *stream);

@@ -910,3 +910,32 @@ def test_mamba_split_conv1d_scan_combined_runs_on_the_matrix_pipe(gpu, monkeypat
         if names[k] == "norm_w" and not rms:
             continue
         assert rel_l2(a.grad.float().cpu(), b.grad) <= 4e-2, (names[k], rel_l2(a.grad.float().cpu(), b.grad))
+
+
+def test_block_passthrough_gradients_equal_autograd_sums(gpu, monkeypatch):
+    """The pass-through LayerNorm nodes (block_ops.PASSTHROUGH: the second consumer's gradient is added inside dm_ln_mod_bwd)
+    against the same model with autograd's own gradient sums -- including the long skips, where AddBackward hands ONE gradient
+    tensor to two nodes (the residual's gradient must only be read): every parameter gradient and the input gradient agree."""
+    from diffma_amd import block_ops
+    from diffma_amd.diffusion import create_diffusion
+
+    g, sd, net, inp = _g5(gpu)
+    net.train()
+    d = create_diffusion("")
+    z, nz, tt = (torch.from_numpy(g[k]).to(gpu) for k in ("loss_z", "loss_noise", "loss_t"))
+
+    def run(flag):
+        monkeypatch.setattr(block_ops, "PASSTHROUGH", flag)
+        net.zero_grad(set_to_none=True)
+        zz = z.clone().requires_grad_(True)
+        loss = d.training_losses(net, zz, tt, dict(y=inp["y"], y2=inp["y2"], w=inp["w"]), noise=nz)["loss"].mean()
+        loss.backward()
+        return float(loss), zz.grad.clone(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    la, ga, pa = run(True)
+    lb, gb, pb = run(False)
+    assert la == lb
+    torch.testing.assert_close(ga, gb, rtol=1e-5, atol=1e-7)
+    assert pa.keys() == pb.keys()
+    for k in pa:
+        torch.testing.assert_close(pa[k], pb[k], rtol=2e-5, atol=1e-7, msg=lambda m, k=k: f"{k}: {m}")
