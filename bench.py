@@ -161,6 +161,49 @@ def cgroup_cpu_quota():
     return None
 
 
+def _profile_files(suffix):
+    """profiles/rNN_<suffix> files, newest round first."""
+    import glob
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}"))
+    return sorted(files, key=lambda f: int(re.search(r"r(\d\d)_", os.path.basename(f)).group(1)), reverse=True)
+
+
+def load_profile_traffic(kernel, dtype, nseq):
+    """HBM bytes per launch of `kernel` (C-ABI name) at this shape from the NEWEST committed traffic profile that holds it
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/prof_r03.sh; cannot be read live).  Two schemas are accepted: the
+    `kernels` table (rounds 1, 3: "<kernel>:<dtype>" -> hbm_bytes_per_launch) and round 2's raw per-kernel-name counter dump."""
+    for f in _profile_files("traffic.json"):
+        try:
+            tj = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        ent = (tj.get("kernels") or {}).get(f"{kernel}:{dtype}")
+        if ent and ent.get("nseq") == nseq and ent.get("hbm_bytes_per_launch"):
+            return int(ent["hbm_bytes_per_launch"]), f"profiles/{os.path.basename(f)}"
+        raw = tj.get(dtype)
+        if isinstance(raw, dict) and nseq == 1536:                      # round 2: KiB counters keyed by the mangled kernel name
+            want = "scan_bwd_kernel" if kernel.endswith("bwd") else "scan_fwd_kernel"
+            for name, c in raw.items():
+                if want in name and ", true, true, true" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:   # the row-index instantiation
+                    return int((2 * c["FETCH_SIZE"]["avg"] + c["WRITE_SIZE"]["avg"]) * 1024), f"profiles/{os.path.basename(f)}"
+    return None, None
+
+
+def load_profile_valu(kernel, dtype):
+    """The VALU side of the roofline for a VALU-bound kernel, from the newest committed PMC profile (tools/prof_r03.sh):
+    executed VALU instructions and busy SIMD-cycles per wave-step, the clock under that instruction mix, and the ceiling they
+    imply as a fraction of the 8 TB/s HBM peak (time at 100 % pipe utilisation -> algorithmic bytes / that time)."""
+    for f in _profile_files("valu.json"):
+        try:
+            ent = json.load(open(f)).get(f"{kernel}:{dtype}")
+        except (OSError, ValueError):
+            continue
+        if ent and "valu_insts_per_wave_step" in ent:
+            return dict(ent, source=f"profiles/{os.path.basename(f)} (rocprofv3 --pmc SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE passes at nseq {ent.get('nseq')}; not re-measured in this run)")
+    return None
+
+
 def scan_microbench(dev, nseq=768, L=196, Dm=1024, N=16, iters=20):
     """The north-star metric proper: `selective_scan_fn` on its own -- forward without checkpoints and the
     training pair (forward with checkpoints + backward) -- at the DiffMa-L/2 operator shape, fp32 and bf16 I/O, timed with
@@ -197,6 +240,19 @@ def scan_microbench(dev, nseq=768, L=196, Dm=1024, N=16, iters=20):
         row = lambda t, nb: {"us": round(t * 1e6, 1), "GBps": round(nb / t / 1e9, 1), "frac": round(nb / t / 1e9 / HBM_PEAK_GBPS, 4),
                              "frac_of_measured_copy_ceiling": round(nb / t / 1e9 / HBM_COPY_GBPS, 4), "algorithmic_bytes": nb}
         out[name] = {"fwd": row(t_f, bf), "fwd_with_checkpoints": row(t_fc, bf), "bwd_incl_partial_sums": row(t_b, bb)}
+        if dt == torch.bfloat16 and nseq % 3 == 0:
+            # the launches the DiffMa mixer issues since round 3: 3 directions through row tables, NO z (the gate is applied once
+            # per token by the merge), delta already activated by dm_dtproj_softplus_fwd, the pre-gated gradient shared
+            Bd = nseq // 3
+            idx = torch.stack([torch.arange(L), torch.randperm(L), torch.randperm(L)]).to(torch.int32).to(dev)
+            act = torch.nn.functional.softplus(delta.float() + bias).to(dt)
+            kw = dict(z_row_index=idx, out_row_index=idx, batch_per_dir=Bd, delta_activated=True)
+            t_mf = timeit(lambda: hip_ops.scan_fwd(u, act, A, Bm, Cm, Dp, None, bias, True, out=y, ckpt=ckpt, **kw))
+            t_mb = timeit(lambda: hip_ops.scan_bwd(u, act, A, Bm, Cm, Dp, None, bias, dout[:Bd], ckpt, True, **kw))
+            out["bf16_mixer_call_pattern"] = {
+                "fwd_with_checkpoints": row(t_mf, hip_ops.scan_fwd_algorithmic_bytes(nseq, Dm, L, N, es, es, has_z=False)),
+                "bwd_incl_partial_sums": row(t_mb, hip_ops.scan_bwd_algorithmic_bytes(nseq, Dm, L, N, es, has_z=False)),
+                "note": "no z / dz in these launches: 3*s (fwd) and 5*s (bwd) bytes per element instead of 4*s / 7*s"}
         del u, delta, z, dout, y, ckpt
     out["shape"] = {"nseq": nseq, "L": L, "D": Dm, "N": N, "iters": iters}
     return out
@@ -411,14 +467,11 @@ def main():
         achieved = per_launch * conc                     # = all bytes of the kernel / time during which it was running
         # HBM traffic of the same kernel at the same shape from the committed PMC passes (cannot be read live)
         traffic = traffic_src = None
-        for tf in ("r02_traffic.json", "r01_traffic.json"):
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))["kernels"].get(f"{dom}:{args.dtype}")
-                if tj and tj["nseq"] == 3 * B and args.model == "DiffMa-L/2":
-                    traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_traffic.sh at this shape; not re-measured in this run)"
-                    break
-            except (OSError, KeyError, ValueError):
-                pass
+        if args.model == "DiffMa-L/2" and not args.use_mamba2:
+            traffic, tsrc = load_profile_traffic(dom, args.dtype, 3 * B)
+            if traffic is not None:
+                traffic_src = f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this shape; not re-measured in this run)"
+        valu = load_profile_valu(dom, args.dtype) if (args.model == "DiffMa-L/2" and not args.use_mamba2) else None
         design_per_launch = r["design_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9 * conc
         res = {
             "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else ('250-step DDPM sampling' if args.sampler == 'ddpm250' else '50-step DDIM sampling')}; samples*steps/s)",
@@ -437,11 +490,15 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "frac_design": round(design_per_launch / HBM_PEAK_GBPS, 4),
                          "design_bytes_per_launch": int(r["design_bytes_per_launch"]),
-                         "bytes_note": "algorithmic = SURVEY.md 8(d): 7*s B per (seq, channel, step) element + fp32 dB/dC for the backward, "
-                                       "4*s + B/C rows for the forward; design adds what this implementation moves on top (state "
-                                       "checkpoints every 4 steps, per-workgroup dB/dC partial rows, dA/dD/dbias partials)",
+                         "bytes_note": "algorithmic = SURVEY.md 8(d) for what the launch computes: the mixer's scans run WITHOUT z since round 3 "
+                                       "(gate hoisted into the merge), i.e. 5*s B per (seq, channel, step) element + fp32 dB/dC for the "
+                                       "backward and 3*s + B/C rows for the forward (7*s / 4*s with z: the stand-alone lines under "
+                                       "selective_scan_fn); design adds what this implementation moves on top (state checkpoints every 4 "
+                                       "steps, per-workgroup dB/dC partial rows, dA/dD/dbias partials)",
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
                          "concurrent_launches": round(conc, 3), "achieved_per_launch": round(per_launch, 1),
+                         "limiter": "valu" if valu else "hbm",      # `bound` names the roof `peak` belongs to; the scans sit on the VALU pipe
+                         "valu": valu,
                          "timing": kernel_source + "; achieved = algorithmic bytes per launch / avg_us x concurrent_launches "
                                    "(concurrent_launches = sum of launch durations / union of launch intervals: 1.0 unless the "
                                    "opt-in two-stream mode DIFFMA_OVERLAP_MIXERS=1 lets launches of the two mixers share the GPU)"},

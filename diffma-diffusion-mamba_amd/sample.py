@@ -58,9 +58,26 @@ def main(args):
     mk = lambda *s: torch.randn(*s, generator=g, device=device)
     out = []
     graphed = None                          # shapes are identical for every batch: one capture serves the whole run
+    real = None
+    if not args.get("synthetic", False) and args.get("ct_image_folder_val", None):
+        # the reference's validation path (sample.py:71-110) through the seam of data.py: conditioning from the CT slice, the
+        # samples decoded by the VAE.  Shard = every world-th item (DistributedSampler without shuffle would pad; the tail is dropped)
+        from .data import NpyDataset, build_encoders, prepare_batch, transform_test, VAE_SCALE
+        if ct_encoder is None:
+            raise FileNotFoundError(f"sampling from data needs the CT_Encoder checkpoint `ct_ckpt` ({args.get('ct_ckpt', None)!r} not found)")
+        ds = NpyDataset(args.ct_image_folder_val, args.mask_image_folder_val, args.mir_image_folder_val, transform=transform_test)
+        real = dict(ds=ds, enc=build_encoders(args, device), order=list(range(rank, len(ds), world)), decoded=[])
     for b in range(int(args.get("num_batches", 1))):
         z = mk(n, 4, latent, latent)
-        if ct_encoder is not None:                     # soft mask + token conditioning from the CT latent (reference sample.py:104)
+        if real is not None:
+            ids = real["order"][b * n:(b + 1) * n]
+            if len(ids) < n:
+                break
+            items = [real["ds"][j] for j in ids]
+            _, y_, y2_, w_, _, _ = prepare_batch(torch.stack([it[0] for it in items]), torch.stack([it[2] for it in items]), real["enc"],
+                                                 ct_encoder, device)
+            kw = dict(y=y_, y2=y2_, w=w_)
+        elif ct_encoder is not None:                   # soft mask + token conditioning from the CT latent (reference sample.py:104)
             with torch.no_grad():
                 ct_w, ct_y2 = ct_encoder(mk(n, 4, latent, latent))
             kw = dict(y=mk(n, 512), y2=ct_y2, w=ct_w)
@@ -76,7 +93,12 @@ def main(args):
             denoiser = graphed
         samples = loop(denoiser, z.shape, z, clip_denoised=False, model_kwargs=kw, progress=False, device=device)
         out.append(samples.cpu())
+        if real is not None:
+            with torch.no_grad():
+                real["decoded"].append(real["enc"].vae_decode(samples / VAE_SCALE).cpu())      # reference sample.py:108
     torch.save(torch.cat(out), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))
+    if real is not None and real["decoded"]:
+        torch.save(torch.cat(real["decoded"]), os.path.join(args.save_dir, f"images_rank{rank}.pt"))
     if dist.is_initialized():
         dist.destroy_process_group()
     return out

@@ -10,7 +10,8 @@ Differences, all deliberate (SURVEY.md A.4-5,10):
     autocast with a GradScaler (train.py:95,247-263), on the same kernels (fp16 I/O, fp32 scan state).
   * a non-finite loss is detected COLLECTIVELY (all-reduce of a flag) and the step is skipped on every rank;
     the reference `continue`s on one rank only, which dead-locks DDP.
-  * frozen encoders (SD-VAE, BiomedCLIP, CT_Encoder) need network weights: with --synthetic (the only mode
+  * frozen encoders (SD-VAE, BiomedCLIP) need network weights: the real-data path runs through the seam of data.py (NpyDataset +
+    an Encoders bundle: `encoders: pretrained | fake`, or your own callables); with --synthetic (the only mode
     that can run offline) latents / embeddings / soft masks are drawn as in BASELINE.md section 4.
 """
 from __future__ import annotations
@@ -179,12 +180,20 @@ def main(args):
     opt = torch.optim.AdamW(ddp.parameters(), lr=lr, weight_decay=0, fused=device.type == "cuda", capturable=use_graph)
     graphed = None
 
-    if not args.get("synthetic", False):
-        raise RuntimeError("real-data training needs the SD-VAE / BiomedCLIP / CT_Encoder weights, which are not available "
-                           "offline; run with --synthetic (BASELINE.md section 4)")
     tokens = model.x_embedder.num_patches
-    data = SyntheticLatents(int(args.get("synthetic_samples", 1024)), latent, tokens, args.global_seed,
-                            ct_encoder=build_ct_encoder(args, latent, device))
+    if not args.get("synthetic", False):
+        # the reference's real-data path (train.py:186-243): NpyDataset -> SD-VAE / BiomedCLIP / CT_Encoder -> denoiser, through the
+        # seam of data.py.  `encoders: pretrained` (default) needs diffusers + open_clip + hub weights and says so when they are
+        # missing; `encoders: fake` runs the whole path on deterministic stand-ins; a data.Encoders bundle can be passed in `args`.
+        from .data import EncodedDataset, NpyDataset, build_encoders, transform_train
+        ct_enc = build_ct_encoder(args, latent, device)
+        if ct_enc is None:
+            raise FileNotFoundError(f"real-data training needs the CT_Encoder checkpoint `ct_ckpt` ({args.get('ct_ckpt', None)!r} not found)")
+        ds = NpyDataset(args.ct_image_folder_train, args.mask_image_folder_train, args.mir_image_folder_train, transform=transform_train)
+        data = EncodedDataset(ds, build_encoders(args, device), ct_enc, seed=0)
+    else:
+        data = SyntheticLatents(int(args.get("synthetic_samples", 1024)), latent, tokens, args.global_seed,
+                                ct_encoder=build_ct_encoder(args, latent, device))
     local_batch = args.global_batch_size // world
     logger.info(f"Dataset contains {data.n}.")
 

@@ -201,3 +201,106 @@ def test_kernel_timer_union_of_launch_intervals():
     assert union_length([(0.0, 2.0), (1.0, 3.0)]) == 3.0                       # two launches sharing the GPU
     assert union_length([(5.0, 6.0), (0.0, 10.0), (2.0, 3.0)]) == 10.0         # nested, unsorted input
     assert union_length([(0.0, 1.0), (1.0, 2.0)]) == 2.0                       # back to back
+
+
+def test_bench_reads_the_newest_committed_profiles():
+    """bench.py's roofline.traffic / roofline.valu come from profiles/: the NEWEST round's file that holds the kernel must be the
+    one cited (VERDICT r2 weak #9: the reader silently fell back to round 1 because round 2's file had another schema)."""
+    import glob
+    import json
+    import re
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rounds = lambda suffix: sorted(int(re.search(r"r(\d\d)_", os.path.basename(f)).group(1)) for f in glob.glob(os.path.join(root, "profiles", f"r[0-9][0-9]_{suffix}")))
+    nbytes, src = bench.load_profile_traffic("dm_selective_scan_bwd", "bf16", 1536)
+    newest = max(rounds("traffic.json"))
+    assert nbytes and nbytes > 1e9 and src == f"profiles/r{newest:02d}_traffic.json", (nbytes, src)
+    # both schemas parse: the `kernels` table (rounds 1 and 3) and round 2's raw counter dump
+    for r in rounds("traffic.json"):
+        tj = json.load(open(os.path.join(root, "profiles", f"r{r:02d}_traffic.json")))
+        assert ("kernels" in tj and "dm_selective_scan_bwd:bf16" in tj["kernels"]) or "bf16" in tj
+    if rounds("valu.json"):
+        v = bench.load_profile_valu("dm_selective_scan_bwd", "bf16")
+        assert v and v["valu_insts_per_wave_step"] > 50 and 0 < v["valu_ceiling_frac_of_8TBps"] < 1 and f"r{max(rounds('valu.json')):02d}_valu.json" in v["source"]
+
+
+# ---- SURVEY.md 8f-4: the data path around the denoiser (NpyDataset + frozen-encoder seam), with deterministic fakes ----------
+def _write_slices(root, n, size=224, float_mri=True):
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    for sub in ("B", "C", "A"):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    for i in range(n):
+        name = f"s{i:03d}.npy"
+        np.save(os.path.join(root, "B", name), rng.integers(0, 256, (size, size), dtype=np.uint8))               # CT
+        np.save(os.path.join(root, "C", name), rng.choice([-1.0, 1.0], (size, size)).astype(np.float32))         # mask in {-1, 1}
+        np.save(os.path.join(root, "A", name), (rng.random((size, size)) * (3.0 if float_mri else 1.0)).astype(np.float32))   # MRI (out of [-1, 1])
+
+
+def test_npy_dataset_and_encoder_seam(tmp_path):
+    """NpyDataset (reference load_data.py:14-38: same file name in three folders, mask -> (mask + 1) / 2) and prepare_batch
+    (train.py:228-243) with the deterministic stand-in encoders: shapes, scale conventions, the MRI range fix-up."""
+    from diffma_amd import data
+    from diffma_amd.ct_encoder import CT_Encoder
+
+    _write_slices(str(tmp_path), 5)
+    ds = data.NpyDataset(str(tmp_path / "B"), str(tmp_path / "C"), str(tmp_path / "A"), transform=data.transform_test)
+    assert len(ds) == 5 and ds.images == sorted(ds.images)
+    ct, mask, mri = ds[3]
+    assert ct.shape == mask.shape == mri.shape == (1, 224, 224)
+    assert 0.0 <= float(ct.min()) and float(ct.max()) <= 1.0                            # uint8 -> [0, 1] like to_tensor
+    assert set(torch.unique(mask).tolist()) <= {0.0, 1.0}                               # (mask + 1) / 2
+    small = data.transform_test(*[t.numpy()[0] for t in (ct, mask, mri)], size=(112, 112))
+    assert all(t.shape == (1, 112, 112) for t in small)                                 # the resize branch
+    enc = data.FakeEncoders(seed=0).bundle()
+    torch.manual_seed(0)
+    ct_enc = CT_Encoder(img_size=28, patch_size=2, in_channels=4, embed_dim=512, contain_mask_token=True).eval()
+    items = [ds[i] for i in range(4)]
+    z, y, y2, w, ct3, mri3 = data.prepare_batch(torch.stack([it[0] for it in items]), torch.stack([it[2] for it in items]), enc, ct_enc, "cpu")
+    assert z.shape == (4, 4, 28, 28) and y.shape == (4, 512) and y2.shape == (4, 196, 512) and w.shape == (4, 196, 1)
+    assert ct3.shape == (4, 3, 224, 224) and float(mri3.min()) == -1.0 and float(mri3.max()) == 1.0      # range fix-up of train.py:236-237
+    assert float(w.min()) > 0.0 and float(w.max()) < 1.0
+    # the stand-in VAE: decode is a right inverse of encode on latents, with the reference's 0.18215 convention
+    back = enc.vae_encode(enc.vae_decode(z / data.VAE_SCALE))
+    torch.testing.assert_close(back, z, rtol=1e-3, atol=1e-4)
+    with pytest.raises(RuntimeError, match="diffusers"):
+        data.pretrained_encoders(device="cpu")                                          # offline: says what is missing
+
+
+def _real_data_worker(rank, world, port, tmpdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+
+    import diffma_amd.mamba as mamba_mod
+    from diffma_amd import sample as sample_mod
+    from diffma_amd import train as train_mod
+    from diffma_amd.config import Config
+
+    mamba_mod.spiral_ssm = _oracle_spiral_ssm                     # test-only substitution (see module docstring)
+    torch.set_num_threads(2)
+    _write_slices(os.path.join(tmpdir, "data"), 4)
+    d = os.path.join(tmpdir, "data")
+    base = dict(model="DiffMa-S/7", image_size=224, dt_rank=16, d_state=16, global_seed=0, synthetic=False, synthetic_ct_encoder=True,
+                encoders="fake", ct_image_folder_train=f"{d}/B", mask_image_folder_train=f"{d}/C", mir_image_folder_train=f"{d}/A",
+                ct_image_folder_val=f"{d}/B", mask_image_folder_val=f"{d}/C", mir_image_folder_val=f"{d}/A")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    steps = train_mod.main(Config(global_batch_size=2, lr=1e-4, lr_=1e-4, epochs=1, accumulation_steps=1, log_every=1, ckpt_every=2,
+                                  results_dir=os.path.join(tmpdir, "res"), init_from_pretrain_ckpt=False, pretrain_ckpt_path="",
+                                  init_train_steps=0, autocast=False, max_steps=2, **base))
+    assert steps == 2
+    ck = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmpdir) for f in fs if f.endswith("0000002.pt"))
+    out = sample_mod.main(Config(ckpt=ck[0], load_ckpt_type="ema", save_dir=os.path.join(tmpdir, "samples"), seed=0,
+                                 sample_global_batch_size=2, sample_num_steps=2, num_batches=1, **base))
+    assert out[0].shape == (2, 4, 28, 28)
+    img = torch.load(os.path.join(tmpdir, "samples", "images_rank0.pt"))
+    assert img.shape == (2, 3, 224, 224) and torch.isfinite(img).all()
+
+
+def test_train_and_sample_on_the_real_data_path_with_fake_encoders(tmp_path):
+    """train.main / sample.main with `synthetic: false`: .npy slices -> NpyDataset -> (stand-in) VAE / CLIP + CT_Encoder -> denoiser,
+    and the sampler's VAE decode at the end (reference train.py:186-243, sample.py:71-110)."""
+    mp.spawn(_real_data_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
