@@ -136,7 +136,7 @@ __device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
 // softplus(raw + bias) (DM_FLAG_DELTA_ACTIVATED: the producer of delta applied it once per element instead of every scan
 // direction twice); the returned ddelta is the gradient of the RAW value in every mode: softplus'(x) = 1 - exp(-softplus(x)).
 template <typename T, typename TBC, int N, int SPLIT, bool HAS_Z, bool IDX, int DMODE, bool ASH = false>
-__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(N <= 16 ? 2 : 1))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
+__global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu((N / SPLIT <= 8 && N == 16) ? 3 : (N <= 16 ? 2 : 1)))) void scan_bwd_kernel(const dm_scan_bwd_args p) {
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
     constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M % 16 == 0;   // dB/dC lane-group sums on the matrix pipe
@@ -551,7 +551,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : 1; };   // lanes per channel
+#ifndef DM_K2_SPLIT16
+#define DM_K2_SPLIT16 1        // lanes per channel at d_state 16: 2 = half the states per lane (<= 168 VGPRs, 3 waves per SIMD); measured in round 3, see DESIGN.md
+#endif
+template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : (N == 16 ? DM_K2_SPLIT16 : 1); };   // lanes per channel
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {
