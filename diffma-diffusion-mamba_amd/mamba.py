@@ -111,7 +111,10 @@ class Mamba(nn.Module):
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
-        if torch.is_grad_enabled() or (xz.is_cuda and torch.cuda.is_current_stream_capturing()):
+        A = self.__dict__.pop("_A_step", None)       # made for all mixers at once by step_prep.prepare (DiffMa.forward), used once
+        if A is not None and A.device == xz.device and torch.is_grad_enabled():
+            pass
+        elif torch.is_grad_enabled() or (xz.is_cuda and torch.cuda.is_current_stream_capturing()):
             A = -torch.exp(self.A_log.float())       # inside a capture A is recomputed IN the graph: replays follow A_log
         else:                                        # inference: A only changes when A_log does (two tiny kernels per call otherwise)
             cache = getattr(self, "_A_cache", None)  # (hipGraph replays of an optimizer do not bump _version: GraphedTrainStep drops the cache)
@@ -130,7 +133,9 @@ class Mamba(nn.Module):
         Bsz, L, _ = hidden_states.shape
         gather, extra = self._baseline_tables(scan_type, L, hidden_states.device)
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
-        A = -torch.exp(self.A_log.float())
+        A = self.__dict__.pop("_A_step", None)
+        if A is None or A.device != xz.device or not torch.is_grad_enabled():
+            A = -torch.exp(self.A_log.float())
         ssm = lambda inp, **kw: spiral_ssm(inp, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                                            self.dt_proj.bias, A, self.D, gather, **kw)
         proj = lambda y: linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)

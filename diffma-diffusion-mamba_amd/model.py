@@ -154,6 +154,9 @@ class DiffMa(nn.Module):
 
     def forward(self, x, t, y, y2, w):
         """x (N,C,H,W) latents; t (N,) timesteps; y (N,D) CLIP embedding; y2 (N,T,D) CT tokens; w (N,T,1) soft mask."""
+        if x.is_cuda and torch.is_grad_enabled():
+            from . import step_prep
+            step_prep.prepare(self)                    # A = -exp(A_log) of every mixer and the 16-bit weight copies: a few foreach launches
         x = self.x_embedder(x) + self.pos_embed
         t = self.t_embedder(t)
         c = torch.cat((t + y, t + y2.mean(dim=1)), dim=1)

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip_ops
+from .step_prep import cast_weight
 
 
 def _to_token_major(t: torch.Tensor) -> torch.Tensor:
@@ -191,7 +192,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         dev = x.device.type
         dt_ = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x.dtype
         xc = x if x.dtype == dt_ else x.to(dt_)
-        wc = weight if weight.dtype == dt_ else weight.to(dt_)
+        wc = cast_weight(weight, dt_)                    # the step's shadow copy when current (step_prep), else a cast
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
         return GemmChain.run(F.linear, xc, wc, None if bias is None else bias.to(dt_))
@@ -245,7 +246,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         dt_ = xz.dtype
         x_view, z_view = xz[..., :Din], xz[..., Din:]
         need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
-        Wx_c, Wdt_c = Wx.to(dt_), Wdt.to(dt_)                                  # kept for the backward (one cast per step, not two)
+        Wx_c, Wdt_c = cast_weight(Wx, dt_), cast_weight(Wdt, dt_)              # kept for the backward (the step's shadows, or one cast per step)
         if hip_ops.conv_xproj_supported(x_view, Wx_c, ndir * Bsz):
             # gather + conv + SiLU + x_proj in one kernel: x~ is projected while its tile is still on the CU
             xc, x_dbl = hip_ops.gather_conv1d_xproj_fwd(x_view, conv_w, conv_b, Wx_c, row_index=scan_index, ndir=ndir, silu=True)

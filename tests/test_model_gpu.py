@@ -939,3 +939,40 @@ def test_block_passthrough_gradients_equal_autograd_sums(gpu, monkeypatch):
     assert pa.keys() == pb.keys()
     for k in pa:
         torch.testing.assert_close(pa[k], pb[k], rtol=2e-5, atol=1e-7, msg=lambda m, k=k: f"{k}: {m}")
+
+
+def test_step_prep_is_bitwise_neutral(gpu, monkeypatch):
+    """step_prep.prepare (all mixers' A = -exp(A_log) and the 16-bit weight copies made by a few foreach launches at the top of
+    DiffMa.forward) changes launch counts only: loss and every gradient of a bf16-autocast training step are IDENTICAL with and
+    without it, and a weight written after prepare() is never served from a stale shadow."""
+    from diffma_amd import step_prep
+    from diffma_amd.diffusion import create_diffusion
+
+    g, sd, net, inp = _g5(gpu)
+    net.train()
+    d = create_diffusion("")
+    z, nz, tt = (torch.from_numpy(g[k]).to(gpu) for k in ("loss_z", "loss_noise", "loss_t"))
+
+    def run(flag):
+        monkeypatch.setattr(step_prep, "ENABLED", flag)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = d.training_losses(net, z, tt, dict(y=inp["y"], y2=inp["y2"], w=inp["w"]), noise=nz)["loss"].mean()
+        loss.backward()
+        return float(loss), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}
+
+    la, pa = run(True)
+    lb, pb = run(False)
+    assert la == lb and pa.keys() == pb.keys()
+    for k in pa:
+        assert torch.equal(pa[k], pb[k]), k
+    # staleness: after an in-place update the shadow must not be handed out
+    w = net.blocks[0].mamba1.in_proj.weight
+    monkeypatch.setattr(step_prep, "ENABLED", True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        step_prep.prepare(net)
+    assert step_prep.shadow_of(w, torch.bfloat16) is not None
+    with torch.no_grad():
+        w.add_(1.0)
+    assert step_prep.shadow_of(w, torch.bfloat16) is None
+    assert torch.equal(step_prep.cast_weight(w, torch.bfloat16), w.to(torch.bfloat16))
