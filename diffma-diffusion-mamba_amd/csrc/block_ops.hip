@@ -142,11 +142,16 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
             if (p.scale) ld_vec<TM, VEC>(sc[it], (const TM*)p.scale + (int64_t)b * p.mod_sb + c);
         }
     }
+    // The gradient that is ADDED to dx (dx_add: the read-only second gradient of x; accumulate: what dx / dx2 already hold) is
+    // requested at the top of the row iteration with the other operands: behind the two row reductions -- where round 2 loaded it --
+    // it cost a second full memory latency per row (the wave owns one row at a time, every iteration is a dependent chain).
+    // (A register prefetch of the whole next row was tried: 100 -> 166 VGPRs at C = 512, 176 -> 266 at C = 1024 -- occupancy lost.)
+    const bool has_old = p.dx_add != nullptr || p.accumulate != 0;
     for (int lr = row0 + wave; lr < row1; lr += LN_WAVES) {
         const int64_t r = (int64_t)b * p.rows_per_batch + lr;
         const float mean = p.stats[2 * r], rstd = p.stats[2 * r + 1];
         const float mk = p.mask ? io<TM>::ld((const TM*)p.mask + r) : 1.f;
-        float xh[NIT][VEC], dxh[NIT][VEC];
+        float xh[NIT][VEC], dxh[NIT][VEC], old[NIT][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -156,6 +161,11 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
                 ld_vec<TX, VEC>(xv, row_src((const TX*)p.x, (const TX*)p.x2, r, p.x_sr, p.x2_sr, p.C1, c));
                 ld_vec<TY, VEC>(d1, (const TY*)p.dy1 + r * p.y_sr + c);
                 if (p.dy2) ld_vec<TY, VEC>(d2, (const TY*)p.dy2 + r * p.y_sr + c);
+                if (has_old) {
+                    const TX* src = p.dx_add ? (const TX*)p.dx_add + r * p.dxa_sr + c
+                                             : ((c < p.C1) ? (const TX*)p.dx + r * p.dx_sr + c : (const TX*)p.dx2 + r * p.dx2_sr + (c - p.C1));
+                    ld_vec<TX, VEC>(old[it], src);
+                }
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     xh[it][j] = (xv[j] - mean) * rstd;
@@ -184,16 +194,9 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) o[j] = rstd * (dxh[it][j] - m1 - xh[it][j] * m2);
                 TX* dst = (c < p.C1) ? (TX*)p.dx + r * p.dx_sr + c : (TX*)p.dx2 + r * p.dx2_sr + (c - p.C1);
-                if (p.dx_add) {                       // read-only second gradient of x (C2 == 0: validated)
-                    float old[VEC];
-                    ld_vec<TX, VEC>(old, (const TX*)p.dx_add + r * p.dxa_sr + c);
+                if (has_old) {
 #pragma unroll
-                    for (int j = 0; j < VEC; ++j) o[j] += old[j];
-                } else if (p.accumulate) {
-                    float old[VEC];
-                    ld_vec<TX, VEC>(old, dst);
-#pragma unroll
-                    for (int j = 0; j < VEC; ++j) o[j] += old[j];
+                    for (int j = 0; j < VEC; ++j) o[j] += old[it][j];
                 }
                 st_vec<TX, VEC>(dst, o);
             }
