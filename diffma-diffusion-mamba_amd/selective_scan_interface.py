@@ -176,11 +176,14 @@ def _tn_splitk_impl(a, b):
     Split K into C slabs with one bmm and add the slabs in fp32; C is bounded so that the slab outputs stay
     small next to the operands."""
     M = a.shape[0]
+
+    def slabs(t, C):
+        """[M, P] (row stride >= P: a column block of a wider row-major buffer is fine, bmm takes the leading dimension) -> [C, M/C, P]"""
+        return t.as_strided((C, M // C, t.shape[1]), (M // C * t.stride(0), t.stride(0), 1))
+
     for C in (64, 32, 16, 8):
-        if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23):
-            pa = a.view(C, M // C, a.shape[1]).transpose(1, 2)
-            pb = b.view(C, M // C, b.shape[1])
-            return torch.bmm(pa, pb).sum(0, dtype=torch.float32)      # the cast is fused into the reduction
+        if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23) and a.stride(1) == 1 and b.stride(1) == 1:
+            return torch.bmm(slabs(a, C).transpose(1, 2), slabs(b, C)).sum(0, dtype=torch.float32)      # the cast is fused into the reduction
     return (a.t() @ b).float()
 
 
@@ -323,7 +326,7 @@ class _SpiralSSMFn(torch.autograd.Function):
                 dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
         dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
-        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R].contiguous()).to(Wdt.dtype)      # [Din, R]
+        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R]).to(Wdt.dtype)                   # [Din, R]; the dt columns of x_dbl in place (leading dimension R + 2N)
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz):
             # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]
