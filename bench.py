@@ -497,6 +497,12 @@ def main():
                                        "steps, per-workgroup dB/dC partial rows, dA/dD/dbias partials)",
                          "avg_us": round(r["avg_us"], 2), "algorithmic_bytes_per_launch": int(r["bytes_per_launch"]),
                          "concurrent_launches": round(conc, 3), "achieved_per_launch": round(per_launch, 1),
+                         # the round-over-round yardstick: SURVEY.md 8(d)'s figure for the operator WITH z (7*s backward / 4*s forward per
+                         # element) over this launch's time -- the z / dz bytes themselves are moved by dm_token_merge / dm_gate_bwd now
+                         "frac_8d_with_z": (round((hip_ops.scan_bwd_algorithmic_bytes(3 * B, 1024, tokens, 16, 2, True) if dom.endswith("bwd")
+                                                   else hip_ops.scan_fwd_algorithmic_bytes(3 * B, 1024, tokens, 16, 2, 2, True))
+                                                  / (r["avg_us"] * 1e-6) / 1e9 * conc / HBM_PEAK_GBPS, 4)
+                                            if (dom.startswith("dm_selective_scan") and args.model.startswith("DiffMa-") and amp and not args.use_mamba2) else None),
                          "limiter": "valu" if valu else "hbm",      # `bound` names the roof `peak` belongs to; the scans sit on the VALU pipe
                          "valu": valu,
                          "timing": kernel_source + "; achieved = algorithmic bytes per launch / avg_us x concurrent_launches "

@@ -12,11 +12,13 @@ been written since (its `_version` is compared: a stale or unknown weight falls 
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
 ENABLED = os.environ.get("DIFFMA_STEP_PREP", "1") == "1"
-_SHADOWS = {}            # id(master parameter) -> (shadow tensor, master version when copied, weakref-free: parameters live as long as the model)
+_SHADOWS = {}            # id(master) -> (weakref to the master, shadow tensor, master version when copied); the weakref guards against
+                         # id() reuse after a model is freed (a NEW parameter with the id and version of a dead one must not get its shadow)
 
 
 class _NegExpAll(torch.autograd.Function):
@@ -45,8 +47,13 @@ class _NegExpAll(torch.autograd.Function):
 def shadow_of(weight, dtype):
     """The 16-bit copy made by the last prepare() if the master is unchanged since, else None."""
     ent = _SHADOWS.get(id(weight))
-    if ent is not None and ent[1] == weight._version and ent[0].dtype == dtype and ent[0].device == weight.device:
-        return ent[0]
+    if ent is None:
+        return None
+    if ent[0]() is not weight:                      # the entry belongs to a parameter that no longer exists
+        del _SHADOWS[id(weight)]
+        return None
+    if ent[2] == weight._version and ent[1].dtype == dtype and ent[1].device == weight.device and ent[1].shape == weight.shape:
+        return ent[1]
     return None
 
 
@@ -90,4 +97,4 @@ def prepare(model):
         with torch.no_grad():
             torch._foreach_copy_(sh, [w.detach() for w in plan["masters"]])
         for w, s in zip(plan["masters"], sh):
-            _SHADOWS[id(w)] = (s, w._version)
+            _SHADOWS[id(w)] = (weakref.ref(w), s, w._version)

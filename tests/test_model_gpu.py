@@ -976,3 +976,9 @@ def test_step_prep_is_bitwise_neutral(gpu, monkeypatch):
         w.add_(1.0)
     assert step_prep.shadow_of(w, torch.bfloat16) is None
     assert torch.equal(step_prep.cast_weight(w, torch.bfloat16), w.to(torch.bfloat16))
+    # id() reuse: an entry left behind by a freed parameter must never serve a new parameter that got its address
+    import weakref
+    dead = torch.nn.Parameter(torch.zeros(4, 4, device=gpu))
+    fresh = torch.nn.Parameter(torch.ones(4, 4, device=gpu))
+    step_prep._SHADOWS[id(fresh)] = (weakref.ref(dead), torch.zeros(4, 4, device=gpu, dtype=torch.bfloat16), fresh._version)
+    assert step_prep.shadow_of(fresh, torch.bfloat16) is None and id(fresh) not in step_prep._SHADOWS
