@@ -17,6 +17,7 @@ import weakref
 import torch
 
 ENABLED = os.environ.get("DIFFMA_STEP_PREP", "1") == "1"
+_PLANS = weakref.WeakKeyDictionary()
 _SHADOWS = {}            # id(master) -> (weakref to the master, shadow tensor, master version when copied); the weakref guards against
                          # id() reuse after a model is freed (a NEW parameter with the id and version of a dead one must not get its shadow)
 
@@ -69,7 +70,7 @@ def prepare(model):
     """Called at the top of DiffMa.forward when gradients are on and the model is on a ROCm device."""
     if not ENABLED:
         return
-    plan = model.__dict__.get("_step_plan")
+    plan = _PLANS.get(model)                        # per model, outside its __dict__: deepcopy / state_dict never see it
     if plan is None:
         from .mamba import Mamba
         mixers = [m for m in model.modules() if isinstance(m, Mamba)]
@@ -83,7 +84,7 @@ def prepare(model):
             net = getattr(m, "attention_network", None)
             if net is not None:
                 masters += [net[1].weight, net[3].weight]
-        plan = model.__dict__["_step_plan"] = dict(mixers=mixers, masters=masters, shadows={})
+        plan = _PLANS[model] = dict(mixers=mixers, masters=masters, shadows={})
     mixers = plan["mixers"]
     if mixers:
         As = _NegExpAll.apply(*[m.A_log for m in mixers])
