@@ -26,9 +26,13 @@
 #include <type_traits>
 #include "dm_common.h"
 
+#ifndef DM_K2_ONE_FENCE
+#define DM_K2_ONE_FENCE 0        // one asm fence over all 16 dA accumulators instead of 16 (s_nop 130 -> 56 per 8 steps, +33 moves): no change in time (2574-2584 us both), off
+#endif
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
-#endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads
+#endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
+                               // 32 dB/dC products and conversions kept but no MFMA / LDS write / flush
 
 namespace dm {
 
@@ -546,8 +550,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
+#if !DM_K2_ONE_FENCE
                     dA[k].x = opaque(dA[k].x);                   // accumulate NOW: left alone the scheduler defers all 8 steps'
                     dA[k].y = opaque(dA[k].y);                   // products to the chunk end and keeps 64 VGPRs alive for them
+#endif
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
                     if constexpr (TRRED) {
@@ -564,6 +570,18 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                     h[k] = hp;
                 }
+#if DM_K2_ONE_FENCE
+                // accumulate dA NOW (left alone the scheduler defers all 8 steps' products to the chunk end and keeps 64 VGPRs alive
+                // for them).  ONE empty asm statement over all accumulators: hipcc follows every inline-asm statement with an
+                // `s_nop 0`, and the per-register form of rounds 1-2 cost 16 of them per step (130 of the loop's ~2 100 instructions).
+                if constexpr (NPL == 8) {
+                    asm volatile("" : "+v"(dA[0].x), "+v"(dA[0].y), "+v"(dA[1].x), "+v"(dA[1].y), "+v"(dA[2].x), "+v"(dA[2].y), "+v"(dA[3].x), "+v"(dA[3].y),
+                                      "+v"(dA[4].x), "+v"(dA[4].y), "+v"(dA[5].x), "+v"(dA[5].y), "+v"(dA[6].x), "+v"(dA[6].y), "+v"(dA[7].x), "+v"(dA[7].y));
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NPL; ++k) { dA[k].x = opaque(dA[k].x); dA[k].y = opaque(dA[k].y); }
+                }
+#endif
                 const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[j];
                 const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
                 const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
@@ -583,6 +601,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                 }
                 if constexpr (DM_K2_EXP & 1) {
+                } else if constexpr ((DM_K2_EXP & 32) != 0 && MFMA_RED) {       // products + conversions only: no MFMA, no LDS write (flush: bit 2)
+#pragma unroll
+                    for (int k = 0; k < M / 2; ++k) asm volatile("" ::"v"(pk_all[k]));
                 } else if constexpr (TRRED) {
                     // (1) multiply the image staged by the PREVIOUS step (j + 1): its LDS writes retired a whole step ago
                     if (j < CK - 1) tr_multiply((j + 1) & 1, j + 1);
@@ -615,7 +636,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int k = 0; k < H0W; ++k) hnext[k] = h0w[0][k];
         if (!(DM_K2_EXP & 2)) __syncthreads();
-        if (!(DM_K2_EXP & 3)) flush_dbc(ch);
+        if (!(DM_K2_EXP & 35)) flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);
         if (!(DM_K2_EXP & 2)) __syncthreads();
         buf ^= 1;
