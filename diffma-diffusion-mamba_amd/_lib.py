@@ -129,7 +129,7 @@ def load():
             fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
             if args in ("void", ""):
                 fn.argtypes = []
-            elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels"):   # int -> int helpers
+            elif name in ("dm_conv_nchunk", "dm_scan_bwd_group_channels", "dm_gather_conv1d_xproj_width_supported"):   # int -> int helpers
                 fn.argtypes = [ctypes.c_int]
             elif name in ("dm_ssd_fwd_supported", "dm_ssd_bwd_supported"):
                 fn.argtypes = [ctypes.c_int] * 4

@@ -229,6 +229,14 @@ static int xp_by_width(const dm_conv_xproj_fwd_args& a, hipStream_t st) {
 
 }  // namespace dm
 
+extern "C" int dm_gather_conv1d_xproj_width_supported(int width) {
+#ifdef DM_FAST_BUILD
+    return width == 4;
+#else
+    return width >= 2 && width <= 4;
+#endif
+}
+
 extern "C" int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype) {
     const bool d_ok = dim == 128 || dim == 256 || dim == 512 || dim == 1024;
     return (d_ok && nproj >= 1 && nproj <= 64 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;

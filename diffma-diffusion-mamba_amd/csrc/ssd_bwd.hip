@@ -549,15 +549,20 @@ extern "C" int dm_ssd_bwd(const dm_ssd_bwd_args* args, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(a.nheads, a.nseq), block(SB_THREADS);
     hipError_t e;
-    if (a.io_dtype == DM_BF16) {
-        static const hipError_t once = hipFuncSetAttribute((const void*)ssd_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES);
-        if (once != hipSuccess) { set_error("dm_ssd_bwd: cannot reserve %d bytes of LDS: %s", SB_LDS_BYTES, hipGetErrorString(once)); return DM_ERR_LAUNCH; }
-        hipLaunchKernelGGL((ssd_bwd_kernel<bf16_t>), grid, block, SB_LDS_BYTES, st, a);
-    } else {
-        static const hipError_t once = hipFuncSetAttribute((const void*)ssd_bwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES);
-        if (once != hipSuccess) { set_error("dm_ssd_bwd: cannot reserve %d bytes of LDS: %s", SB_LDS_BYTES, hipGetErrorString(once)); return DM_ERR_LAUNCH; }
-        hipLaunchKernelGGL((ssd_bwd_kernel<f16_t>), grid, block, SB_LDS_BYTES, st, a);
+    // the dynamic-LDS limit of a kernel is a per-DEVICE attribute: set it once per (device, instantiation), not once per process
+    // (a process that launches on a second GPU would otherwise fail there with 79 KB of dynamic LDS -- ADVICE r2)
+    static bool reserved[2][64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { set_error("dm_ssd_bwd: cannot query the current device"); return DM_ERR_LAUNCH; }
+    const int which = a.io_dtype == DM_BF16 ? 0 : 1;
+    if (!reserved[which][dev]) {
+        const hipError_t r = which == 0 ? hipFuncSetAttribute((const void*)ssd_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES)
+                                        : hipFuncSetAttribute((const void*)ssd_bwd_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, SB_LDS_BYTES);
+        if (r != hipSuccess) { set_error("dm_ssd_bwd: cannot reserve %d bytes of LDS: %s", SB_LDS_BYTES, hipGetErrorString(r)); return DM_ERR_LAUNCH; }
+        reserved[which][dev] = true;                  // benign race: two threads may both set the same value
     }
+    if (which == 0) hipLaunchKernelGGL((ssd_bwd_kernel<bf16_t>), grid, block, SB_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((ssd_bwd_kernel<f16_t>), grid, block, SB_LDS_BYTES, st, a);
     e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_ssd_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;

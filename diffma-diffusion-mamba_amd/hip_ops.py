@@ -374,11 +374,11 @@ XPROJ_FUSED_MIN_SEQS = 512
 
 
 # Directions accumulated by the forward scan (DM_FLAG_OUT_ACCUMULATE, one launch per direction) instead of a separate token_merge
-# pass (the chunk-parallel forward for small launches has no accumulating form).
-# Measured (MI355X, DiffMa-L/2, batch 512): the three per-direction launches cost 45.2 ms per step against 39.6 ms for the one
-# 3-direction launch (tails and prologues of three smaller grids; the accumulating kernel needs 139 VGPRs), the merge pass
-# they replace 4.9 ms: a wash (277.6 vs 277.2 ms per step).  Off by default; DIFFMA_ACC_DIRS=1 turns it on.
-ACC_DIRS_MIN_WAVES = 1024 if os.environ.get("DIFFMA_ACC_DIRS") == "1" else None
+# pass: measured a wash in round 2 (the three per-direction launches cost 45.2 ms per step against 39.6 ms for the one 3-direction
+# launch, the merge they replaced 4.9 ms), it rounds the running sum to the I/O dtype after every direction, and since
+# round 3 the merge is where the SiLU(z) gate lives.  The model path no longer takes it (the DIFFMA_ACC_DIRS switch is gone); the
+# kernel flag stays in the ABI and keeps its kernel-level test (scan_fwd(..., acc_dirs=True)).
+ACC_DIRS_MIN_WAVES = None
 
 
 def scan_acc_dirs_ok(u, ndir, N, a_shared=False):
@@ -386,9 +386,12 @@ def scan_acc_dirs_ok(u, ndir, N, a_shared=False):
     return (ACC_DIRS_MIN_WAVES is not None and ndir > 1 and N == 16 and not a_shared and S * ((Dm + 63) // 64) >= ACC_DIRS_MIN_WAVES)
 
 
-def conv_xproj_supported(x, wx, nseq):
-    """True when dm_gather_conv1d_xproj_fwd serves this call (16-bit I/O, dim in {128..1024}, <= 64 projection rows)."""
+def conv_xproj_supported(x, wx, nseq, width=4):
+    """True when dm_gather_conv1d_xproj_fwd serves this call (16-bit I/O, dim in {128..1024}, <= 64 projection rows, an
+    instantiated conv width: once the fused path is chosen there is no fallback, so the predicate must know -- ADVICE r2)."""
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or nseq < XPROJ_FUSED_MIN_SEQS:
+        return False
+    if not _lib.load().dm_gather_conv1d_xproj_width_supported(int(width)):
         return False
     if x.stride(0) % 2 or x.stride(1) % 2 or x.storage_offset() % 2:
         return False
@@ -432,9 +435,16 @@ def gather_conv1d_xproj_fwd(x, weight, bias, wx, *, row_index=None, ndir=1, silu
 XPROJ_FUSED_BWD = os.environ.get("DIFFMA_FUSED_CONV_BWD", "1") == "1"
 
 
-def conv_xproj_bwd_supported(x, wx, nseq):
-    """True when dm_gather_conv1d_xproj_bwd serves this call (as the forward, plus a projection width that is a multiple of 8)."""
+def conv_xproj_bwd_supported(x, wx, nseq, width=4, du=None, dxdbl=None):
+    """True when dm_gather_conv1d_xproj_bwd serves this call (as the forward, plus a projection width that is a multiple of 8 and
+    the alignment the C side checks on the gradient operands: du rows on 4-byte, dx_dbl rows on 16-byte boundaries)."""
     if not XPROJ_FUSED_BWD:
+        return False
+    if not _lib.load().dm_gather_conv1d_xproj_width_supported(int(width)):
+        return False
+    if du is not None and (du.data_ptr() % 4 or du.stride(0) % 2 or du.stride(1) % 2 or du.stride(2) != 1):
+        return False
+    if dxdbl is not None and (dxdbl.data_ptr() % 16 or dxdbl.stride(0) % 8 or dxdbl.stride(1) != 1):
         return False
     if not x.is_cuda or x.dtype not in (torch.bfloat16, torch.float16) or nseq < XPROJ_FUSED_MIN_SEQS:
         return False

@@ -250,7 +250,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         x_view, z_view = xz[..., :Din], xz[..., Din:]
         need_grad = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[1:8]))   # grad_on: the caller's grad mode
         Wx_c, Wdt_c = cast_weight(Wx, dt_), cast_weight(Wdt, dt_)              # kept for the backward (the step's shadows, or one cast per step)
-        if hip_ops.conv_xproj_supported(x_view, Wx_c, ndir * Bsz):
+        if hip_ops.conv_xproj_supported(x_view, Wx_c, ndir * Bsz, conv_w.shape[-1]):
             # gather + conv + SiLU + x_proj in one kernel: x~ is projected while its tile is still on the CU
             xc, x_dbl = hip_ops.gather_conv1d_xproj_fwd(x_view, conv_w, conv_b, Wx_c, row_index=scan_index, ndir=ndir, silu=True)
         else:
@@ -328,7 +328,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
         dWdt = _tn_splitk(ddelta2, x_dbl[:, :R]).to(Wdt.dtype)                   # [Din, R]; the dt columns of x_dbl in place (leading dimension R + 2N)
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
-        if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz):
+        if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz, conv_w.shape[-1], du, dx_dbl):
             # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]
             merged_dx = hip_ops.DX_MERGED and ndir > 1 and conv_w.shape[-1] == 4
             dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_xproj_bwd(xz[..., :Din], conv_w, conv_b, du, dx_dbl, Wx_c.t().contiguous(),

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 21
+#define DM_ABI_VERSION 22
 
 typedef enum {
     DM_OK = 0,
@@ -255,6 +255,7 @@ typedef struct {
 
 int dm_gather_conv1d_xproj_fwd(const dm_conv_xproj_fwd_args *args, void *stream);
 int dm_gather_conv1d_xproj_supported(int dim, int nproj, int io_dtype);
+int dm_gather_conv1d_xproj_width_supported(int width);   /* conv widths the fused forward AND backward are instantiated for */
 
 /* Backward of the conv FUSED with the x_proj input gradient: the gradient entering the conv is
  *   dxc[s][l][:] = du[s][l][:] + dxdbl[s*seqlen + l][:] @ wx            (d x~ = dL/du + d x_dbl . x_proj.weight)

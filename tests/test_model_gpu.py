@@ -714,7 +714,6 @@ def test_fused_conv_xproj_path_in_the_mixer(gpu, monkeypatch):
         return real_b(*a, **k)
 
     monkeypatch.setattr(hip_ops, "XPROJ_FUSED_MIN_SEQS", 1)
-    monkeypatch.setattr(hip_ops, "ACC_DIRS_MIN_WAVES", 1)              # and the directions accumulated inside the forward scan
     monkeypatch.setattr(hip_ops, "XPROJ_FUSED_BWD", True)
     monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_fwd", counted)
     monkeypatch.setattr(hip_ops, "gather_conv1d_xproj_bwd", counted_b)
