@@ -38,16 +38,24 @@ template <typename T> struct io;
 template <> struct io<float> {
     static __device__ __forceinline__ float ld(const float* p) { return *p; }
     static __device__ __forceinline__ void st(float* p, float x) { *p = x; }
+    // the element as loaded / its conversion at the point of use (a value fetched ahead must stay untouched until its consumer:
+    // a conversion next to the load puts an s_waitcnt vmcnt(0) right behind it)
+    static __device__ __forceinline__ uint32_t ld_raw(const float* p) { return __float_as_uint(*p); }
+    static __device__ __forceinline__ float cv(uint32_t w) { return __uint_as_float(w); }
 };
 template <> struct io<bf16_t> {
     static __device__ __forceinline__ float ld(const bf16_t* p) {
         return __uint_as_float(((uint32_t)p->v) << 16);
     }
     static __device__ __forceinline__ void st(bf16_t* p, float x) { p->v = (uint16_t)f32_to_bf16_bits(x); }
+    static __device__ __forceinline__ uint32_t ld_raw(const bf16_t* p) { return (uint32_t)p->v; }
+    static __device__ __forceinline__ float cv(uint32_t w) { return __uint_as_float(w << 16); }
 };
 template <> struct io<f16_t> {
     static __device__ __forceinline__ float ld(const f16_t* p) { return (float)p->v; }
     static __device__ __forceinline__ void st(f16_t* p, float x) { p->v = (_Float16)x; }
+    static __device__ __forceinline__ uint32_t ld_raw(const f16_t* p) { return (uint32_t)__builtin_bit_cast(unsigned short, p->v); }
+    static __device__ __forceinline__ float cv(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (unsigned short)w); }
 };
 
 // Wave-uniform read-only operands (B_l, C_l rows, index tables) are read through the CONSTANT address
@@ -72,11 +80,46 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, /*num_records*/ -1, 0x00020000);
 }
+// 2 GB window: a lane whose VGPR offset is BIO_OOB is out of range -- its load returns 0 and its store is dropped.  Lets a kernel
+// predicate a memory access per lane (or per wave) WITHOUT a branch around it: hipcc's s_waitcnt bookkeeping loses count at every
+// control-flow join whose arms issued different numbers of memory operations, and a prefetch pipeline depends on exact counts.
+constexpr int BIO_OOB = (int)0x80000000u;
+__device__ __forceinline__ rsrc_t make_rsrc_2g(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), /*stride*/ 0, /*num_records*/ (int)0x80000000u, 0x00020000);
+}
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// W 32-bit words of a lane (W % 4 == 0) as 16-byte buffer accesses, group g of 4 words at byte offset g * gstride: with
+// gstride = 16 * (lanes in a row) every instruction reads / writes one dense run of 16-byte pieces.  (The lane-contiguous form,
+// 32 bytes per lane written by two instructions at a 32-byte lane stride, halves the instruction count as well but leaves every
+// 32-byte sector half-written per instruction: the forward scan got 7.5 % slower with it.)
+template <int W>
+__device__ __forceinline__ void bio_st_words(const uint32_t (&w)[W], rsrc_t r, int voff, int soff, int gstride) {
+    static_assert(W % 4 == 0, "whole 16-byte groups");
+#pragma unroll
+    for (int g = 0; g < W / 4; ++g) {
+        const u32x4_t q = {w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff + g * gstride, 0);
+    }
+}
+template <int W>
+__device__ __forceinline__ void bio_ld_words(uint32_t (&w)[W], rsrc_t r, int voff, int soff, int gstride) {
+    static_assert(W % 4 == 0, "whole 16-byte groups");
+#pragma unroll
+    for (int g = 0; g < W / 4; ++g) {
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + g * gstride, 0);
+        w[4 * g] = q[0]; w[4 * g + 1] = q[1]; w[4 * g + 2] = q[2]; w[4 * g + 3] = q[3];
+    }
+}
 template <typename T> struct bio;
 template <> struct bio<float> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
         return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
     }
+    // the loaded word as it is (a prefetched value must not be touched before its consumer: any arithmetic on it puts the
+    // wait for the load right behind the load) and its conversion at the point of use
+    typedef uint32_t raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    static __device__ __forceinline__ float cv(raw_t w) { return __uint_as_float(w); }
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
     }
@@ -86,6 +129,9 @@ template <> struct bio<bf16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
         return __uint_as_float(((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)) << 16);
     }
+    typedef unsigned short raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    static __device__ __forceinline__ float cv(raw_t w) { return __uint_as_float((uint32_t)w << 16); }
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
         uint32_t b;
         asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(b) : "v"(x));       // low half is what store_b16 writes
@@ -98,6 +144,14 @@ template <> struct bio<bf16_t> {
 template <> struct bio<f16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
         const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+        _Float16 h;
+        __builtin_memcpy(&h, &b, 2);
+        return (float)h;
+    }
+    typedef unsigned short raw_t;
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    static __device__ __forceinline__ float cv(raw_t w) {
+        const unsigned short b = w;
         _Float16 h;
         __builtin_memcpy(&h, &b, 2);
         return (float)h;

@@ -196,7 +196,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) vo
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
                 if constexpr (CK_PACKED) {
-                    w[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * (N / 2) + k) * p.dim) * 4, 0);
+                    if (k % 4 == 0) {                            // [chunk][N/8][d][4 words]: 16 bytes at a time
+                        const u32x4_t qv = __builtin_amdgcn_raw_buffer_load_b128(r_ck, vo_ck * 4, (slot * (N / 8) + k / 4) * p.dim * 16, 0);
+                        w[k] = qv[0]; w[k + 1] = qv[1]; w[k + 2] = qv[2]; w[k + 3] = qv[3];
+                    }
                 } else {
                     w[2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k) * p.dim) * 4, 0);
                     w[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k + 1) * p.dim) * 4, 0);

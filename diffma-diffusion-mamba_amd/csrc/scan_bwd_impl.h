@@ -23,6 +23,15 @@
 //      of a slice and the 4 waves and stored as one row of partials per (step, workgroup = 256 channels at d_state 16);
 //      the workgroups of a sequence are summed by the caller (deterministic).
 // One sweep over u, delta, z, dout (read) and du, ddelta, dz (write): 28 B/element in fp32 + checkpoints.
+//
+// Memory pipeline (round 3): all global loads run one stage ahead of their use -- the inputs and the checkpoint of the NEXT
+// sub-chunk, the B/C rows of the next chunk, the row-table entries two sub-chunks ahead -- and every memory instruction of the
+// loop is issued unconditionally: lanes / steps / slots that must not take part use an out-of-range buffer offset (BIO_OOB in a
+// 2 GB window: loads return 0, stores are dropped).  Both halves matter.  hipcc's s_waitcnt pass counts outstanding operations
+// exactly only along straight-line code; at every join whose arms issued different numbers of memory operations (a uniform
+// `if` around the stores of a tail step, a zero-or-load checkpoint, a conditional fetch) it falls back to the smaller count, and
+// with ~50 operations in flight a prefetched value was then waited for with vmcnt(19) right after 20 newer loads had been
+// issued -- i.e. for a load that had just left.  (profiles/r03_k2_experiments.txt #9.)
 #include <type_traits>
 #include "dm_common.h"
 
@@ -32,7 +41,7 @@
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
 #endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
-                               // 32 dB/dC products and conversions kept but no MFMA / LDS write / flush
+                               // 32 dB/dC products and conversions kept but no MFMA / LDS write / flush, 64 no u / delta / dy loads
 
 namespace dm {
 
@@ -88,7 +97,6 @@ __device__ __forceinline__ void lane_group_reduce(float (&v)[M]) {
 // 12 permlane swaps + 12 adds of lane_group_reduce, on the otherwise idle matrix pipe.  The products are rounded to bf16
 // first (they are re-rounded to the 16-bit I/O dtype later anyway); fp32 I/O keeps the exact VALU path.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return dm_cvt_pk_bf16(lo, hi);
 }
@@ -109,6 +117,10 @@ __device__ __forceinline__ f32x4 mfma_group_sum16(const u32x4_t& a_lo, const u32
 // make a value opaque to the optimiser (costs no instruction): stops it from keeping the exp() / B-row
 // values of the recompute pass alive across the whole chunk just to save recomputing them
 __device__ __forceinline__ float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ uint32_t opaque_u(uint32_t x) {
     asm volatile("" : "+v"(x));
     return x;
 }
@@ -144,16 +156,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
     constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M % 16 == 0;   // dB/dC lane-group sums on the matrix pipe
-    // KEEPA: the decay factors a = exp(delta*A) the recompute pass evaluates for the first SUB-1 steps of a sub-chunk are kept for
-    // the reverse sweep as fp16 pairs (8 VGPRs per step instead of 16 v_exp_f32 + 8 v_pk_mul_f32 evaluated a second time); the
-    // sweep multiplies with them through v_fma_mix_f32.  16-bit I/O only: a in (0, 1] rounded to 11 bits is far inside what the
-    // I/O rounding of the gradients leaves (the fp32 instantiation keeps evaluating them exactly).
-#ifndef DM_K2_KEEPA
-#define DM_K2_KEEPA 0          // recompute steps whose factors are kept (the LAST ones of the pass); measured (MI355X, nseq 1536): 0: 2717-2745 us, 1: 2702-2719, 2: 2765-2768, 3: spills, 4370 -- the kernel is not limited by its VALU instruction count (profiles/r03_k2_experiments.txt), so this is OFF
-#endif
-    constexpr bool KEEPA = DM_K2_KEEPA > 0 && sizeof(T) == 2 && N == 16 && SPLIT == 1 && !ASH && DMODE == 2;
-    constexpr int KEEP0 = SUB - 1 - DM_K2_KEEPA;               // first kept step of a sub-chunk
-    typedef _Float16 a_h2 __attribute__((ext_vector_type(2)));
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
@@ -205,18 +207,22 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     const rsrc_t r_dt = make_rsrc((const T*)p.delta + (int64_t)s * p.dt_ss);
     const rsrc_t r_z = make_rsrc(HAS_Z ? (const T*)p.z + (int64_t)sb * p.z_ss : nullptr);
     const rsrc_t r_g = make_rsrc((const T*)p.dout + (int64_t)((IDX && !(p.flags & DM_FLAG_DOUT_PER_SEQ)) ? sb : s) * p.do_ss);
-    const rsrc_t r_du = make_rsrc((T*)p.du + (int64_t)s * p.du_ss);
-    const rsrc_t r_ddt = make_rsrc((T*)p.ddelta + (int64_t)s * p.ddt_ss);
-    const rsrc_t r_dz = make_rsrc(HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);
+    // (stores, checkpoint loads and the dB/dC partial rows go through 2 GB windows: predication by an out-of-range offset, no branch)
+    const rsrc_t r_du = make_rsrc_2g((T*)p.du + (int64_t)s * p.du_ss);
+    const rsrc_t r_ddt = make_rsrc_2g((T*)p.ddelta + (int64_t)s * p.ddt_ss);
+    const rsrc_t r_dz = make_rsrc_2g(HAS_Z ? (T*)p.dz + (int64_t)s * p.dz_ss : nullptr);
     const TBC* __restrict__ Bg = (const TBC*)p.B + (int64_t)s * p.B_ss + (int64_t)grp * p.B_sg;
     const TBC* __restrict__ Cg = (const TBC*)p.C + (int64_t)s * p.C_ss + (int64_t)grp * p.C_sg;
     // checkpoints: the state entering every SUB-step sub-chunk; fp32 rows [n][d] or, for bf16 I/O, rows [n/2][d] of bf16 pairs
     constexpr bool CK_PACKED = std::is_same<T, bf16_t>::value;
     constexpr int CK_ROWS = CK_PACKED ? N / 2 : N;
     const int nck = (L + SUB - 1) / SUB;
-    const rsrc_t r_ck = make_rsrc(p.ckpt ? (const uint32_t*)p.ckpt + (int64_t)s * nck * CK_ROWS * p.dim : nullptr);
+    const rsrc_t r_ck = make_rsrc_2g(p.ckpt ? (const uint32_t*)p.ckpt + (int64_t)s * nck * CK_ROWS * p.dim : nullptr);
+    const rsrc_t r_dbc = make_rsrc_2g(p.dBC_partial + (int64_t)s * L * gridDim.x * (2 * N));
     const int vo = d * ES;                 // per-lane byte offset of the channel, shared by all T tensors
-    const int vo_ck = (d + q * (CK_ROWS / SPLIT) * p.dim) * 4;   // the slice offset is per lane: keep it in the VGPR part of the address
+    const int vo_st = (active && q == 0) ? vo : BIO_OOB;       // the lane that owns the channel's du / ddelta / dz
+    // (fp32 rows [n][d]; packed: [N/8][d][4 words], 16 bytes per lane and access.  The slice offset is per lane, so it lives in the VGPR part of the address)
+    const int vo_ck = CK_PACKED ? (d * 4 + q * (CK_ROWS / SPLIT / 4) * p.dim * 4) * 4 : (d + q * (CK_ROWS / SPLIT) * p.dim) * 4;
     const int sl_u = (int)p.u_sl * ES, sl_dt = (int)p.dt_sl * ES, sl_z = (int)p.z_sl * ES, sl_g = (int)p.do_sl * ES;
     const int sl_du = (int)p.du_sl * ES, sl_ddt = (int)p.ddt_sl * ES, sl_dz = (int)p.dz_sl * ES;
     const int i_B_sl = (int)p.B_sl, i_C_sl = (int)p.C_sl;
@@ -284,54 +290,60 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 
     // B/C rows of a chunk: CK*2N values, fetched cooperatively (one or two per thread), one chunk ahead
     constexpr int BC_PER_THREAD = (CK * 2 * N + 64 * BWD_WAVES - 1) / (64 * BWD_WAVES);
-    auto fetch_bc = [&](int chunk, float(&v)[BC_PER_THREAD]) {
+    // (raw words, one unconditional load per element through a selected pointer: the conversion happens in stash_bc, a chunk later.
+    //  Until round 3 the load sat in a conditional block together with its bf16 -> fp32 shift, the compiler kept the two together
+    //  and every chunk began with `global_load_ushort; s_waitcnt vmcnt(0)` -- a full memory latency, with everything older drained.)
+    auto fetch_bc = [&](int chunk, uint32_t(&v)[BC_PER_THREAD]) {
 #pragma unroll
         for (int i = 0; i < BC_PER_THREAD; ++i) {
-            const int e = tid + i * 64 * BWD_WAVES;
+            int e = tid + i * 64 * BWD_WAVES;
+            e = (e < CK * 2 * N) ? e : CK * 2 * N - 1;
             const int j = e / (2 * N), cc = e % (2 * N);
             int l = chunk * CK + j;
             l = (l < L) ? l : L - 1;
-            v[i] = 0.f;
-            if (e < CK * 2 * N) v[i] = (cc < N) ? io<TBC>::ld(Bg + l * i_B_sl + cc) : io<TBC>::ld(Cg + l * i_C_sl + cc - N);
+            const TBC* src = (cc < N) ? Bg + l * i_B_sl + cc : Cg + l * i_C_sl + (cc - N);
+            v[i] = io<TBC>::ld_raw(src);
         }
     };
-    auto stash_bc = [&](int b, const float(&v)[BC_PER_THREAD]) {
+    auto stash_bc = [&](int b, const uint32_t(&v)[BC_PER_THREAD]) {
 #pragma unroll
         for (int i = 0; i < BC_PER_THREAD; ++i) {
             const int e = tid + i * 64 * BWD_WAVES;
-            if (e < CK * 2 * N) bc_lds[b][e / (2 * N)][e % (2 * N)] = v[i];
+            if (e < CK * 2 * N) bc_lds[b][e / (2 * N)][e % (2 * N)] = io<TBC>::cv(v[i]);
         }
     };
     // sum chunk `chunk`'s staged products over the workgroup's waves and over the row positions of a slice,
     // and store its dB/dC partial rows
     auto flush_dbc = [&](int chunk) {
         const int l0 = chunk * CK;
-        for (int e = tid; e < CK * 2 * N; e += 64 * BWD_WAVES) {
-            const int j = e / (2 * N), cc = e % (2 * N);
-            if (l0 + j < L) {
-                if constexpr (TRRED) {
-                    float acc = 0.f;
 #pragma unroll
-                    for (int w = 0; w < BWD_WAVES; ++w) acc += red_lds[w][j][cc];
-                    p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
-                    continue;
-                }
+        for (int it = 0; it < BC_PER_THREAD; ++it) {
+            const int e_ = tid + it * 64 * BWD_WAVES;
+            const bool in = e_ < CK * 2 * N;
+            const int e = in ? e_ : 0;
+            const int j = e / (2 * N), cc = e % (2 * N);
+            // rows past the end of the sequence (and threads past the chunk's values) store out of range: dropped, no branch
+            const int vo_p = (in && l0 + j < L) ? (((l0 + j) * nwg + (int)blockIdx.x) * (2 * N) + cc) * 4 : BIO_OOB;
+            float acc = 0.f;
+            if constexpr (TRRED) {
+#pragma unroll
+                for (int w = 0; w < BWD_WAVES; ++w) acc += red_lds[w][j][cc];
+            } else {
                 const int n = (cc < N) ? cc : cc - N;
                 const int qq = n / NS;
                 const int vidx = (cc < N) ? n % NS : NS + n % NS;                 // value index in [0, M) inside slice qq
                 const int lane0 = (MFMA_RED ? 16 * ((vidx & 15) >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
                 const int reg = MFMA_RED ? 4 * (vidx >> 4) + (vidx & 3) : (vidx >> 2);
-                float acc = 0.f;
 #pragma unroll
                 for (int w = 0; w < BWD_WAVES; ++w)
 #pragma unroll
                     for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(reg >> 2) * RED_HALF + (lane0 + SPLIT * t) * 4 + (lane0 >> 4) * 8 + (reg & 3)];
-                p.dBC_partial[(((int64_t)s * L + l0 + j) * nwg + blockIdx.x) * (2 * N) + cc] = acc;
             }
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), r_dbc, vo_p, 0, 0);
         }
     };
     {
-        float v[BC_PER_THREAD];
+        uint32_t v[BC_PER_THREAD];
         fetch_bc(nchunk - 1, v);
         stash_bc(0, v);
     }
@@ -342,19 +354,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // (= the state after the last step) for 4 ci == L, zero for ci == 0 and past the end.
     constexpr int H0W = CK_PACKED ? NPL : 2 * NPL;               // 32-bit words per state slice
     auto load_state = [&](int ci, uint32_t(&w)[H0W]) {
-        const int slot = (ci > 0 && ci * SUB < L) ? ci : ((ci > 0 && ci * SUB == L) ? 0 : -1);      // wave-uniform
-        if (slot < 0) {
-#pragma unroll
-            for (int k = 0; k < H0W; ++k) w[k] = 0u;
+        const int slot_ = (ci > 0 && ci * SUB < L) ? ci : ((ci > 0 && ci * SUB == L) ? 0 : -1);      // wave-uniform
+        const int vo_ = (slot_ < 0 || !p.ckpt) ? BIO_OOB : vo_ck;                                    // no slot: the loads return 0 (no branch)
+        const int slot = slot_ < 0 ? 0 : slot_;
+        if constexpr (CK_PACKED) {
+            bio_ld_words<H0W>(w, r_ck, vo_, slot * p.dim * (N / 2) * 4, p.dim * 16);       // dense 16-byte loads
         } else {
 #pragma unroll
             for (int k = 0; k < NPL; ++k) {
-                if constexpr (CK_PACKED) {
-                    w[k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * (N / 2) + k) * p.dim) * 4, 0);
-                } else {
-                    w[2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k) * p.dim) * 4, 0);
-                    w[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_ck, ((slot * N + 2 * k + 1) * p.dim) * 4, 0);
-                }
+                w[2 * k] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_, ((slot * N + 2 * k) * p.dim) * 4, 0);
+                w[2 * k + 1] = __builtin_amdgcn_raw_buffer_load_b32(r_ck, vo_, ((slot * N + 2 * k + 1) * p.dim) * 4, 0);
             }
         }
     };
@@ -370,124 +379,126 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
         }
     };
-    uint32_t hnext[H0W];                                         // state entering the sub-chunk after the current chunk
-    load_state(nchunk * (CK / SUB), hnext);
-    // PFCK: the raw checkpoint words of a chunk are requested one chunk ahead (packed checkpoints only: 16 VGPRs); without it they
-    // are requested at the top of the chunk and the first sub-chunk waits for them
-#ifndef DM_K2_PFCK
-#define DM_K2_PFCK 1          // measured -0.6 % (2588-2592 -> 2572-2574 us)
-#endif
-    constexpr bool PFCK = DM_K2_PFCK && CK_PACKED && N == 16 && SPLIT == 1;
-    uint32_t h0pf[CK / SUB][H0W];
-    if constexpr (PFCK) {
+    // ---- the software pipeline (round 3) ---------------------------------------------------------------------------------
+    // Sub-chunks (SUB steps, one checkpoint) are processed last to first.  While sub-chunk ci is being recomputed and swept, the
+    // u / delta / dout (/ z) values and the checkpoint of sub-chunk ci-1 are already in flight into their own registers -- RAW
+    // words, converted only when ci-1 starts, so that no wait lands behind the loads -- and the row-table entries of sub-chunk
+    // ci-2 into SGPRs.  Until round 3 a chunk's 24 input loads were issued at its top and consumed at once: every wave spent one
+    // full memory latency per 8 steps in s_waitcnt (SQ_WAIT_INST_ANY = 27 % of the wave cycles, the VALU 71 % busy at two waves
+    // per SIMD).  Registers: 12 converted + 12 raw inputs (24 converted before), 3 checkpoint slices (end state | current | next;
+    // 5 before with the chunk-level checkpoint prefetch).
+    static_assert(SUB == 4, "row-table entries of a sub-chunk travel as one 4-dword scalar load");
+    constexpr int NSC = CK / SUB;
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    typedef const i32x4_t __attribute__((address_space(4), aligned(4)))* idx4_ptr;
+    auto load_rows = [&](cptr<int32_t> tab, int ci) -> i32x4_t {          // rows of the steps of sub-chunk ci (clamped to L - 1)
+        const int lb = ci * SUB;
+        i32x4_t r = {0, 0, 0, 0};
+        if (ci < 0) return r;
+        if (IDX && lb + SUB <= L) {
+            r = *(idx4_ptr)(tab + lb);
+        } else {
 #pragma unroll
-        for (int sc = 0; sc < CK / SUB; ++sc) load_state((nchunk - 1) * (CK / SUB) + sc, h0pf[sc]);
-    }
+            for (int i = 0; i < SUB; ++i) {
+                const int l = (lb + i < L) ? lb + i : L - 1;
+                r[i] = IDX ? tab[l] : l;
+            }
+        }
+        return r;
+    };
+    typename bio<T>::raw_t ru[SUB], rd[SUB], rg[SUB], rz[HAS_Z ? SUB : 1];      // raw input words of the sub-chunk in flight
+    uint32_t ck_nx[H0W];                                          // its checkpoint, raw
+    i32x4_t orow_is = load_rows(oidx, nchunk * NSC - 1), zrow_is = {0, 0, 0, 0};       // row-table entries of the sub-chunk to be ISSUED next
+    if (HAS_Z) zrow_is = load_rows(zidx, nchunk * NSC - 1);
+    auto issue_sub = [&](int ci) {          // requests sub-chunk ci (rows in orow_is / zrow_is), then the row entries of ci - 1
+        const int lb = ci < 0 ? 0 : ci * SUB;              // (ci = -1 after the first sub-chunk of the sequence: rows 0.., never used)
+#pragma unroll
+        for (int i = 0; i < SUB; ++i) {
+            const int l = (lb + i < L) ? lb + i : L - 1;
+            if (DM_K2_EXP & 64) { ru[i] = (typename bio<T>::raw_t)opaque_u(0x3f00u); rd[i] = (typename bio<T>::raw_t)opaque_u(0x3c23u); rg[i] = (typename bio<T>::raw_t)opaque_u(0x3dccu); if (HAS_Z) rz[i] = 0; continue; }
+            ru[i] = bio<T>::ld_raw(r_u, vo, l * sl_u);
+            rd[i] = bio<T>::ld_raw(r_dt, vo, l * sl_dt);
+            if (HAS_Z) rz[i] = bio<T>::ld_raw(r_z, vo, zrow_is[i] * sl_z);
+            rg[i] = bio<T>::ld_raw(r_g, vo, orow_is[i] * sl_g);
+        }
+        load_state((DM_K2_EXP & 4) ? -1 : ci, ck_nx);
+        orow_is = load_rows(oidx, ci - 1);
+        if (HAS_Z) zrow_is = load_rows(zidx, ci - 1);
+    };
+    uint32_t ck_end[H0W];                                        // state entering the sub-chunk processed BEFORE this one = this one's end state
+    load_state(nchunk * NSC, ck_end);
+    i32x4_t zrow_nx = zrow_is;                                   // z rows of the sub-chunk in flight (its dz stores need them)
+    issue_sub(nchunk * NSC - 1);
 
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int l0 = ch * CK;
-        float bc_next[BC_PER_THREAD];
-        if (ch > 0) fetch_bc(ch - 1, bc_next);          // lands while this chunk computes
-        // ---- chunk inputs (invalid tail steps become exact no-ops: g = 0 => every adjoint term is 0) ------
-        float uu[CK], dl[CK], zz[CK], gg[CK];
-        int zrow[CK], orow_[CK];
-        if (IDX && l0 + CK <= L) {                          // full chunk: the 8 table entries come as one scalar vector load each
-            typedef int i32x8_t __attribute__((ext_vector_type(8)));
-            typedef const i32x8_t __attribute__((address_space(4), aligned(4)))* idx8_ptr;
-            const i32x8_t zi = *(idx8_ptr)(zidx + l0), oi = *(idx8_ptr)(oidx + l0);
-#pragma unroll
-            for (int j = 0; j < CK; ++j) { zrow[j] = zi[j]; orow_[j] = oi[j]; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < CK; ++j) {
-                const int l = (l0 + j < L) ? l0 + j : L - 1;
-                zrow[j] = IDX ? zidx[l] : l;
-                orow_[j] = IDX ? oidx[l] : l;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            const int l = (l0 + j < L) ? l0 + j : L - 1;
-            const int orow = orow_[j];
-            uu[j] = bio<T>::ld(r_u, vo, l * sl_u);
-            dl[j] = bio<T>::ld(r_dt, vo, l * sl_dt);
-            zz[j] = HAS_Z ? bio<T>::ld(r_z, vo, zrow[j] * sl_z) : 0.f;
-            gg[j] = bio<T>::ld(r_g, vo, orow * sl_g);
-        }
-        // ---- state slices entering the chunk's sub-chunks (sub-chunk 0 of the sequence and sub-chunks past the end: 0) ----
-        // (packed checkpoints stay raw until the sub-chunk starts: unpacking here would put a vmcnt(0) right behind every load)
-        uint32_t h0w[CK / SUB][H0W];
-        if constexpr (PFCK) {
-#pragma unroll
-            for (int sc = 0; sc < CK / SUB; ++sc) {
-#pragma unroll
-                for (int k = 0; k < H0W; ++k) h0w[sc][k] = h0pf[sc][k];
-                if (ch > 0) load_state((ch - 1) * (CK / SUB) + sc, h0pf[sc]);       // lands while this chunk computes
-            }
-        } else {
-#pragma unroll
-            for (int sc = 0; sc < CK / SUB; ++sc) load_state((DM_K2_EXP & 4) ? -1 : ch * (CK / SUB) + sc, h0w[sc]);
-        }
-
-#pragma unroll
-        for (int j = 0; j < CK; ++j) {
-            const bool valid = (l0 + j) < L;
-            float x = dl[j];
-            if (DMODE != 2) x += bias;
-            if (DMODE == 1) x = softplus_f(x);
-            dl[j] = x;                                    // tail steps re-read row L-1: finite garbage that only meets g = 0
-            gg[j] = (valid && active) ? gg[j] : 0.f;
-        }
-        // one forward step of the slice: h <- a*h + B*dl*u   (used by all three recompute passes)
-        uint32_t apk[KEEPA ? DM_K2_KEEPA : 1][KEEPA ? NPL : 1];    // [kept step][state pair]: fp16 pairs
-        auto fwd_step = [&](f32x2(&h)[NPL], int j, int keep) {
-            float Bv[NS];
-            const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
-            if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) Bv[k] = opaque(1.0f); } else
-            lds_ld_vec<NS>(Bv, brow);
-            const float dlo = opaque(dl[j]);
-            const float du = dlo * uu[j];
-            float a_sh = 0.f;
-            if (ASH) a_sh = fast_exp2(A2[0].x * dlo);             // DM_FLAG_A_SHARED: one decay factor for all states of the channel
-#pragma unroll
-            for (int k = 0; k < NPL; ++k) {
-                f32x2 a;
-                if (ASH) {
-                    a = (f32x2){a_sh, a_sh};
-                } else {
-                    const f32x2 t = A2[k] * dlo;
-                    a.x = fast_exp2(t.x);
-                    a.y = fast_exp2(t.y);
-                }
-                if constexpr (KEEPA) { if (keep >= KEEP0) apk[keep - KEEP0][k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, a_h2)); }
-                f32x2 bb;
-                bb.x = Bv[2 * k];
-                bb.y = Bv[2 * k + 1];
-                h[k] = a * h[k] + bb * du;
-            }
-        };
-
+        uint32_t bc_next[BC_PER_THREAD];
+        fetch_bc(ch > 0 ? ch - 1 : 0, bc_next);         // lands while this chunk computes (unconditional: a branch would pin the wait to the load)
         // Sub-chunks of SUB steps, last one first; each starts from its own checkpoint and its SUB states live in
         // registers (hs) during its reverse sweep.
 #pragma unroll
-        for (int sc = CK / SUB - 1; sc >= 0; --sc) {
+        for (int sc = NSC - 1; sc >= 0; --sc) {
+            const int ci = ch * NSC + sc;
+            // ---- take over the sub-chunk that was in flight (invalid tail steps become exact no-ops: g = 0 => every adjoint term is 0)
+            float uu[SUB], dl[SUB], zz[SUB], gg[SUB];
+            uint32_t ck_cur[H0W];
+            const i32x4_t zrow = zrow_nx;
+#pragma unroll
+            for (int i = 0; i < SUB; ++i) {
+                const bool valid = (l0 + sc * SUB + i) < L;
+                uu[i] = bio<T>::cv(ru[i]);
+                float x = bio<T>::cv(rd[i]);
+                if (DMODE != 2) x += bias;
+                if (DMODE == 1) x = softplus_f(x);
+                dl[i] = x;                                    // tail steps re-read row L-1: finite garbage that only meets g = 0
+                zz[i] = HAS_Z ? bio<T>::cv(rz[i]) : 0.f;
+                gg[i] = (valid && active) ? bio<T>::cv(rg[i]) : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < H0W; ++k) ck_cur[k] = ck_nx[k];
+            // ---- request the next one (ci - 1): lands while this one computes
+            zrow_nx = zrow_is;
+            issue_sub(ci - 1);                  // (ci = 0: rows 0 and an out-of-range checkpoint -- harmless, and no branch)
+            // one forward step of the slice: h <- a*h + B*dl*u
+            auto fwd_step = [&](f32x2(&h)[NPL], int i) {
+                float Bv[NS];
+                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + sc * SUB + i) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
+                if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) Bv[k] = opaque(1.0f); } else
+                lds_ld_vec<NS>(Bv, brow);
+                const float dlo = opaque(dl[i]);
+                const float du = dlo * uu[i];
+                float a_sh = 0.f;
+                if (ASH) a_sh = fast_exp2(A2[0].x * dlo);             // DM_FLAG_A_SHARED: one decay factor for all states of the channel
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) {
+                    f32x2 a;
+                    if (ASH) {
+                        a = (f32x2){a_sh, a_sh};
+                    } else {
+                        const f32x2 t = A2[k] * dlo;
+                        a.x = fast_exp2(t.x);
+                        a.y = fast_exp2(t.y);
+                    }
+                    f32x2 bb;
+                    bb.x = Bv[2 * k];
+                    bb.y = Bv[2 * k + 1];
+                    h[k] = a * h[k] + bb * du;
+                }
+            };
             f32x2 h[NPL];
-            unpack_state(h, h0w[sc]);
+            unpack_state(h, ck_cur);
             f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
-            // LAZY0: hs[0] IS the checkpoint, whose raw words stay live anyway (they are the end state of the next sub-chunk to be
-            // processed): with packed checkpoints it is unpacked again when the sweep reaches step 0 (16 shifts / ands per
-            // sub-chunk) instead of occupying 16 VGPRs through the whole sweep -- the registers the kept decay factors live in
-            constexpr bool LAZY0 = KEEPA && CK_PACKED;
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) { if (!(LAZY0 && i == 0)) hs[i][k] = h[k]; }
-                if (i < SUB - 1) fwd_step(h, sc * SUB + i, i);
+                for (int k = 0; k < NPL; ++k) hs[i][k] = h[k];
+                if (i < SUB - 1) fwd_step(h, i);
             }
-            // the state after the sub-chunk's last step is the next sub-chunk's checkpoint: one recomputed step less
-            if (sc == CK / SUB - 1) unpack_state(h, hnext);
-            else unpack_state(h, h0w[sc == CK / SUB - 1 ? sc : sc + 1]);
+            // the state after the sub-chunk's last step is the checkpoint of the sub-chunk processed before: one recomputed step less
+            unpack_state(h, ck_end);
+#pragma unroll
+            for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];
             // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
 #pragma unroll
             for (int i = SUB - 1; i >= 0; --i) {
@@ -500,14 +511,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
                 lds_ld_vec<NS>(Bv, brow);
                 lds_ld_vec<NS>(Cv, brow + N); }
-                const float g = gg[j];
+                const float g = gg[i];
                 float sz = 1.f, gy = g;
                 if (HAS_Z) {
-                    sz = sigmoid_f(zz[j]);
-                    gy = g * zz[j] * sz;
+                    sz = sigmoid_f(zz[i]);
+                    gy = g * zz[i] * sz;
                 }
-                const float dlo = opaque(dl[j]);
-                const float du = dlo * uu[j];
+                const float dlo = opaque(dl[i]);
+                const float du = dlo * uu[i];
                 float a_rev = 0.f;
                 if (ASH) a_rev = fast_exp2(A2[0].x * dlo);
                 f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
@@ -519,34 +530,19 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
                     cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
                     f32x2 a;
-                    const bool kept = KEEPA && i < SUB - 1 && i >= KEEP0;      // compile-time after unrolling
                     if (ASH) {
                         a = (f32x2){a_rev, a_rev};
-                    } else if (!kept) {
+                    } else {
                         const f32x2 t = A2[k] * dlo;
                         a.x = fast_exp2(t.x);
                         a.y = fast_exp2(t.y);
                     }
                     const f32x2 hj = h[k];
-                    f32x2 hp;
-                    if (LAZY0 && i == 0) {
-                        uint32_t w = h0w[sc][k];
-                        asm volatile("" : "+v"(w));              // unpack HERE (an early unpack would re-occupy the registers)
-                        hp.x = __uint_as_float(w << 16);
-                        hp.y = __uint_as_float(w & 0xffff0000u);
-                    } else {
-                        hp = hs[i][k];
-                    }
+                    const f32x2 hp = hs[i][k];
                     if (HAS_Z) yp2 += cc * hj;
                     const f32x2 G = cc * gy + carry[k];          // dL/dh_j
                     const f32x2 dCp = hj * gy;
-                    if (kept) {
-                        const a_h2 ah = __builtin_bit_cast(a_h2, apk[kept ? i - KEEP0 : 0][KEEPA ? k : 0]);
-                        carry[k].x = (float)ah.x * G.x;          // v_fma_mix_f32: the fp16 operand is converted in the multiplier
-                        carry[k].y = (float)ah.y * G.y;
-                    } else {
-                        carry[k] = a * G;                        // a_j * dL/dh_j, flows to step j-1
-                    }
+                    carry[k] = a * G;                            // a_j * dL/dh_j, flows to step j-1
                     const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
@@ -582,22 +578,23 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     for (int k = 0; k < NPL; ++k) { dA[k].x = opaque(dA[k].x); dA[k].y = opaque(dA[k].y); }
                 }
 #endif
-                const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[j];
+                const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[i];
                 const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
                 const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
-                float ddl = uu[j] * GB + LN2 * dlA;
+                float ddl = uu[i] * GB + LN2 * dlA;
                 const float duv = dlo * GB + gy * Dv;
                 if (DMODE != 0) ddl *= (1.0f - fast_exp2(-dlo * LOG2E));   // softplus'(x) = sigmoid(x) = 1 - exp(-softplus(x))
                 if (q == 0) {                                             // one lane per channel owns the channel sums
-                    dD_acc += gy * uu[j];
+                    dD_acc += gy * uu[i];
                     dbias_acc += ddl;
                 }
-                if (valid && active && q == 0) {
-                    if (!(DM_K2_EXP & 8) || duv == 123.456f) bio<T>::st_cv(r_du, vo, l * sl_du, duv);
-                    if (!(DM_K2_EXP & 8) || ddl == 123.456f) bio<T>::st_cv(r_ddt, vo, l * sl_ddt, ddl);
+                {
+                    const int vo_s = valid ? vo_st : BIO_OOB;
+                    if (!(DM_K2_EXP & 8) || duv == 123.456f) bio<T>::st_cv(r_du, vo_s, l * sl_du, duv);
+                    if (!(DM_K2_EXP & 8) || ddl == 123.456f) bio<T>::st_cv(r_ddt, vo_s, l * sl_ddt, ddl);
                     if (HAS_Z) {
-                        const float dzv = g * ypre * sz * (1.0f + zz[j] * (1.0f - sz));
-                        bio<T>::st_cv(r_dz, vo, zrow[j] * sl_dz, dzv);
+                        const float dzv = g * ypre * sz * (1.0f + zz[i] * (1.0f - sz));
+                        bio<T>::st_cv(r_dz, vo_s, zrow[i] * sl_dz, dzv);
                     }
                 }
                 if constexpr (DM_K2_EXP & 1) {
@@ -633,8 +630,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
         }
         if constexpr (TRRED && !(DM_K2_EXP & 1)) tr_multiply(0, 0);       // the chunk's last processed step (j = 0) is still staged
-#pragma unroll
-        for (int k = 0; k < H0W; ++k) hnext[k] = h0w[0][k];
         if (!(DM_K2_EXP & 2)) __syncthreads();
         if (!(DM_K2_EXP & 35)) flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);

@@ -148,13 +148,14 @@ __global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan
             bio<T>::st(r_o, vo, (IDX ? oidx[l] : l) * sl_o, y);
             if (CKPT && ((l + 1) % FWD_CKE == 0 || l + 1 == L)) {       // training: the state entering every 4-step chunk (wave-uniform);
                 const int ci = (l + 1 < L) ? (l + 1) / FWD_CKE : 0;      // slot 0 = the state after the last step
+                if constexpr (CK_PACKED) {                               // [chunk][N/8][d][4 words], see scan_fwd_impl.h
+                    uint32_t w[NP];
 #pragma unroll
-                for (int k = 0; k < NP; ++k) {
-                    if constexpr (CK_PACKED) {
-                        uint32_t w;
-                        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
-                        __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((ci * NP + k) * p.dim) * 4, 0);
-                    } else {
+                    for (int k = 0; k < NP; ++k) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[k]) : "v"(h[k].x), "v"(h[k].y));
+                    bio_st_words<NP>(w, r_ck, d * 16, ci * p.dim * NP * 4, p.dim * 16);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
                         bio<float>::st(r_ck, d * 4, ((ci * N + 2 * k) * p.dim) * 4, h[k].x);
                         bio<float>::st(r_ck, d * 4, ((ci * N + 2 * k + 1) * p.dim) * 4, h[k].y);
                     }

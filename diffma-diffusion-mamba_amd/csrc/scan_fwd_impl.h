@@ -138,13 +138,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((sizeof(T) =
     const int nchunk = CKPT ? (L + FWD_CKE - 1) / FWD_CKE : 0;
     const rsrc_t r_ck = make_rsrc(CKPT ? (const uint32_t*)p.ckpt + (int64_t)s * nchunk * CK_ROWS * p.dim : nullptr);
     auto store_slot = [&](int c) {
+        if constexpr (CK_PACKED) {          // [chunk][N/8][d][4 words]: two dense 16-byte stores per lane (8 dword stores until round 3)
+            uint32_t w[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if constexpr (CK_PACKED) {
-                uint32_t w;
-                asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(h[k].x), "v"(h[k].y));
-                __builtin_amdgcn_raw_buffer_store_b32(w, r_ck, d * 4, ((c * NP + k) * p.dim) * 4, 0);
-            } else {
+            for (int k = 0; k < NP; ++k) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w[k]) : "v"(h[k].x), "v"(h[k].y));
+            bio_st_words<NP>(w, r_ck, d * 16, c * p.dim * NP * 4, p.dim * 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
                 bio<float>::st(r_ck, d * 4, ((c * N + 2 * k) * p.dim) * 4, h[k].x);
                 bio<float>::st(r_ck, d * 4, ((c * N + 2 * k + 1) * p.dim) * 4, h[k].y);
             }

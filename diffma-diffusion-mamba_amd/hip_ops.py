@@ -125,9 +125,9 @@ def scan_nchunk(L: int, every: int = SCAN_CKPT_EVERY) -> int:
 
 def alloc_scan_ckpt(S: int, L: int, N: int, Dm: int, io_dtype, device):
     """Checkpoint buffer of the training forward (include/diffma_hip.h): bf16 I/O stores pairs of bf16 states in
-    one 32-bit word ([S, chunk, N/2, Dm] int32), every other I/O dtype stores fp32 ([S, chunk, N, Dm])."""
+    one 32-bit word ([S, chunk, N/8 * Dm, 4] int32), every other I/O dtype stores fp32 ([S, chunk, N, Dm])."""
     if io_dtype == torch.bfloat16:
-        return torch.empty((S, scan_nchunk(L), N // 2, Dm), dtype=torch.int32, device=device)
+        return torch.empty((S, scan_nchunk(L), (N // 8) * Dm, 4), dtype=torch.int32, device=device)
     return torch.empty((S, scan_nchunk(L), N, Dm), dtype=torch.float32, device=device)
 
 
@@ -221,7 +221,7 @@ def _scan_fwd_launch(u, delta, A, Bm, Cm, D, z, delta_bias, delta_softplus, z_ro
     if accumulate:                               # the running sum is read back once per accumulating launch
         design += S * Dm * L * u.element_size()
     if ckpt is not None:
-        design += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * Dm * 4     # slots 1.. + slot 0 (the final state)
+        design += scan_nchunk(L, ckpt_every) * S * ckpt.shape[2] * ckpt.shape[3] * 4     # slots 1.. + slot 0 (the final state)
     _launch("dm_selective_scan_fwd", a, u, nbytes, design)
     return out
 
@@ -290,7 +290,7 @@ def scan_bwd(u, delta, A, Bm, Cm, D, z, delta_bias, dout, ckpt, delta_softplus=T
     a.ddt_ss, a.ddt_sl, a.ddt_sd = ddelta.stride()
     nbytes = scan_bwd_algorithmic_bytes(S, Dm, L, N, u.element_size(), z is not None)
     design = nbytes + 2 * S * N * L * Bm.element_size() + S * L * (nw - 1) * 2 * N * 4 + 4 * S * Dm * (N + 2) \
-        + (scan_nchunk(L, ckpt_every) - 1 + (L % ckpt_every == 0)) * S * ckpt.shape[2] * Dm * 4   # slot 0 is read when L ends on a boundary
+        + (scan_nchunk(L, ckpt_every) - 1 + (L % ckpt_every == 0)) * S * ckpt.shape[2] * ckpt.shape[3] * 4   # slot 0 is read when L ends on a boundary
     _launch("dm_selective_scan_bwd", a, u, nbytes, design)
     if dbc_out is not None:                     # [S, L, 2N] view in the caller's buffer (the dB | dC columns of d x_dbl): summed + placed in one pass
         dBCs = sum_partials(dBC.view(S * L, nw, 2 * N), dbc_out)

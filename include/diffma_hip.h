@@ -93,8 +93,9 @@ enum {
  *
  * ckpt (optional, training): the state after every ckpt_every (= 4) steps; slot c > 0 holds the state entering
  * step 4*c, slot 0 (the state entering step 0 is zero) the state after the last step.  ckpt_dtype DM_F32: fp32, layout [s][chunk][n][d] (fp32 / fp16 I/O);
- * DM_BF16: pairs of bf16 in one 32-bit word, layout [s][chunk][n/2][d], state 2k in the low half and 2k+1 in
- * the high half (bf16 I/O: the recomputed states inherit the precision the I/O tensors already have).
+ * DM_BF16: pairs of bf16 in one 32-bit word, layout [s][chunk][n/8][d][4] (16-byte accesses per lane, dense per
+ * instruction), state 2k in the low half and 2k+1 in the high half of word k (bf16 I/O: the recomputed states inherit
+ * the precision the I/O tensors already have).  The buffer is private to the forward / backward pair of one build.
  * last_state (optional): final h, fp32, layout [s][n][d].
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
