@@ -91,6 +91,7 @@ dm_gate_bwd_args = _make_struct("dm_gate_bwd_args")
 dm_dtproj_args = _make_struct("dm_dtproj_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
+dm_gate_head_args = _make_struct("dm_gate_head_args")
 dm_rmsnorm_merge_args = _make_struct("dm_rmsnorm_merge_args")
 dm_colsum_args = _make_struct("dm_colsum_args")
 dm_sum_partials_args = _make_struct("dm_sum_partials_args")

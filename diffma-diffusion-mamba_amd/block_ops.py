@@ -113,6 +113,39 @@ def blend_residual(x, xs, ws, a_row, gate):
         return _BlendFn.apply(x, xs, ws, a_row.to(xs.dtype), gate)
 
 
+class _GateHeadFn(torch.autograd.Function):
+    """a = sigmoid(silu(h + b1) @ w2^T + b2) with h the first Linear's output without its bias (csrc/gate_head.hip)."""
+
+    @staticmethod
+    def forward(ctx, h, b1, w2, b2):
+        h = h if h.stride(-1) == 1 else h.contiguous()
+        b1f = None if b1 is None else b1.detach().float().contiguous()
+        w2f = w2.detach().float().reshape(-1).contiguous()
+        b2f = None if b2 is None else b2.detach().float().reshape(-1).contiguous()
+        a = hip_ops.gate_head_fwd(h, b1f, w2f, b2f)
+        ctx.save_for_backward(h, b1f, w2f, a)
+        ctx.meta = (None if b1 is None else b1.dtype, w2.dtype, w2.shape, None if b2 is None else (b2.dtype, b2.shape))
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        h, b1f, w2f, a = ctx.saved_tensors
+        b1_dt, w2_dt, w2_shape, b2_meta = ctx.meta
+        dh, db1, dw2, db2 = hip_ops.gate_head_bwd(da, a, h, b1f, w2f)
+        return (dh, None if b1_dt is None else db1.to(b1_dt), dw2.to(w2_dt).view(w2_shape),
+                None if b2_meta is None else db2.to(b2_meta[0]).view(b2_meta[1]))
+
+
+# DIFFMA_GATE_HEAD=0: the ATen chain (bias epilogue, SiLU, Linear(C, 1), Sigmoid) instead of the fused tail (A/B runs, tests)
+GATE_HEAD = __import__("os").environ.get("DIFFMA_GATE_HEAD", "1") == "1"
+
+
+def gate_head(h, b1, w2, b2):
+    """sigmoid(Linear(C, 1)(silu(h + b1))): the tail of the block's fusion MLP; h [B, L, C] -> [B, L, 1]."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _GateHeadFn.apply(h, b1, w2, b2)
+
+
 _autocast_dtype_cached = [torch.float32]
 
 

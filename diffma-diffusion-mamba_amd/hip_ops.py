@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -716,6 +716,57 @@ def blend_bwd(g, xs, ws, a_row, gate):
     a.g, a.dxs, a.dws, a.da, a.dgate_part = _ptr(g), _ptr(dxs), _ptr(dws), _ptr(da), _ptr(part)
     _launch("dm_blend_bwd", a, g, Bsz * L * C * (g.element_size() + 4 * xs.element_size()))
     return dxs, dws, da, part.sum(1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Tail of the block's fusion MLP: bias + SiLU + Linear(C, 1) + Sigmoid in one pass (csrc/gate_head.hip)
+# ------------------------------------------------------------------------------------------------
+GATE_HEAD_BWD_BLOCKS = 1024          # partial rows of the backward (= its grid: 4 workgroups per CU)
+
+
+def gate_head_supported(h, C=None):
+    """16-byte rows: C a multiple of 4 (fp32) / 8 (16-bit) and at most 1024 / 2048 values."""
+    C = h.shape[-1] if C is None else C
+    vec = 16 // h.element_size()
+    return h.is_cuda and h.dtype in _DT and C % vec == 0 and C <= 64 * vec * 4 and h.stride(-1) == 1
+
+
+def _gate_head_args(h2, b1, w2, b2, a_row):
+    a = dm_gate_head_args()
+    a.rows, a.C, a.io_dtype = h2.shape[0], h2.shape[1], dtype_code(h2)
+    a.h, a.h_sr = _ptr(h2), h2.stride(0)
+    a.b1, a.w2, a.b2, a.a = _ptr(b1), _ptr(w2), _ptr(b2), _ptr(a_row)
+    return a
+
+
+def gate_head_fwd(h, b1, w2, b2):
+    """h [..., C] (the first Linear's output WITHOUT its bias); b1 [C] / None, w2 [C], b2 [1] / None in fp32 -> a [..., 1] (dtype of h)
+    = sigmoid(silu(h + b1) @ w2 + b2)."""
+    _require_gpu(h, b1, w2, b2)
+    C = h.shape[-1]
+    h2 = h.reshape(-1, C)
+    a_row = torch.empty(h.shape[:-1] + (1,), dtype=h.dtype, device=h.device)
+    a = _gate_head_args(h2, b1, w2, b2, a_row)
+    _launch("dm_gate_head_fwd", a, h, h2.numel() * h.element_size() + a_row.numel() * h.element_size())
+    return a_row
+
+
+def gate_head_bwd(da, a_row, h, b1, w2):
+    """-> (dh like h, db1 [C] fp32, dw2 [C] fp32, db2 [1] fp32)."""
+    _require_gpu(da, a_row, h, b1, w2)
+    C = h.shape[-1]
+    h2 = h.reshape(-1, C)
+    da = da.reshape(-1)
+    if da.dtype != h.dtype or not da.is_contiguous():
+        da = da.to(h.dtype).contiguous()
+    dh = torch.empty(h2.shape, dtype=h.dtype, device=h.device)
+    nblk = max(1, min(GATE_HEAD_BWD_BLOCKS, (h2.shape[0] + 3) // 4))
+    part = torch.empty((nblk, 2 * C + 4), dtype=torch.float32, device=h.device)
+    a = _gate_head_args(h2, b1, w2, None, a_row)
+    a.da, a.dh, a.dh_sr, a.part, a.nblk = _ptr(da), _ptr(dh), dh.stride(0), _ptr(part), nblk
+    _launch("dm_gate_head_bwd", a, h, 2 * h2.numel() * h.element_size() + 2 * da.numel() * h.element_size())
+    sums = colsum(part)
+    return dh.view(h.shape), sums[:C], sums[C:2 * C], sums[2 * C:2 * C + 1]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -13,7 +13,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import block_ops
+from . import block_ops, hip_ops
 from .mamba import Mamba
 from .selective_scan_interface import GemmChain, linear_splitk
 
@@ -123,7 +123,11 @@ class Spiral_MambaBlock(nn.Module):
                 hcat, x_ssm, w_ssm = block_ops.ln_cat(x_ssm, w_ssm, net[0], passthrough=True)
             else:
                 hcat = block_ops.ln_cat(x_ssm, w_ssm, net[0])
-            a = net[4](linear_splitk(net[2](linear_splitk(hcat, net[1].weight, net[1].bias)), net[3].weight, net[3].bias))
+            if block_ops.GATE_HEAD and hip_ops.gate_head_supported(hcat, net[1].out_features):
+                # bias + SiLU + Linear(C, 1) + Sigmoid ride on ONE read of the first Linear's output (csrc/gate_head.hip)
+                a = block_ops.gate_head(linear_splitk(hcat, net[1].weight, None), net[1].bias, net[3].weight, net[3].bias)
+            else:
+                a = net[4](linear_splitk(net[2](linear_splitk(hcat, net[1].weight, net[1].bias)), net[3].weight, net[3].bias))
             return block_ops.blend_residual(x, x_ssm, w_ssm, a, gate)
         x_ssm = modulate(self.norm1(x), shift, scale)
         w_ssm = x_ssm * w

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 22
+#define DM_ABI_VERSION 23
 
 typedef enum {
     DM_OK = 0,
@@ -408,6 +408,31 @@ typedef struct {
 
 int dm_blend_fwd(const dm_blend_args *args, void *stream);
 int dm_blend_bwd(const dm_blend_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tail of the block's fusion MLP (block/mamba_block.py:90-91,111-112: attention_network = LayerNorm -> Linear(2C, C) -> SiLU ->
+ * Linear(C, 1) -> Sigmoid).  h = the first Linear's GEMM output WITHOUT its bias, [rows][C] (row stride h_sr):
+ *     dm_gate_head_fwd :  a[r] = sigmoid( sum_c silu(h[r][c] + b1[c]) * w2[c] + b2[0] )
+ *     dm_gate_head_bwd :  dpre = da * a * (1 - a);  dh[r][c] = dpre * w2[c] * silu'(h + b1);  part[blk] = this workgroup's
+ *                         [ sum_r dh (= d b1) | sum_r dpre * silu(h + b1) (= d w2) | sum_r dpre (= d b2), 0, 0, 0 ]
+ * part: [nblk][2*C + 4] fp32, nblk chosen by the caller (it is the grid; rows are dealt round-robin to 4 * nblk waves);
+ * dm_colsum_f32 reduces it.  b1 may be NULL.  C a multiple of 4 (fp32) / 8 (16-bit), C <= 1024 (fp32) / 2048; 16-byte aligned rows.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t rows;
+    int32_t C, io_dtype;                        /* h, a, da, dh                                              */
+    int32_t nblk, _pad;                         /* bwd only                                                  */
+    const void *h;                              /* [rows][C]                                                 */
+    const float *b1, *w2, *b2;                  /* [C] or NULL, [C], [1] or NULL                             */
+    void *a;                                    /* fwd: output [rows]; bwd: input                            */
+    const void *da;                             /* bwd: [rows]                                               */
+    void *dh;                                   /* bwd: [rows][C]                                            */
+    float *part;                                /* bwd: [nblk][2*C + 4]                                      */
+    int64_t h_sr, dh_sr;
+} dm_gate_head_args;
+
+int dm_gate_head_fwd(const dm_gate_head_args *args, void *stream);
+int dm_gate_head_bwd(const dm_gate_head_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Gated-RMSNorm epilogue of the Mamba-2 mixer fused with the 3-way CrossMerge (block/mamba2.py:349,402-403,

@@ -1011,3 +1011,48 @@ def test_sum_partials_matches_torch(gpu, out_dtype, M, nw, C):
     assert float((wide[:, :32] - 3.0).abs().max()) == 0.0
     out3 = torch.empty(M // 1, C, dtype=out_dtype, device=gpu)
     torch.testing.assert_close(hip_ops.sum_partials(parts, out3), ref, **tol)
+
+
+# ---- tail of the block's fusion MLP (csrc/gate_head.hip) vs plain PyTorch in fp64 ---------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,C,with_b1,strided", [(3 * 196, 512, True, False), (37, 64, True, True), (5000, 384, False, False),
+                                                    (130, 1024, True, False), (64, 2048, True, False), (1, 8, True, False)])
+def test_gate_head_matches_torch(gpu, dtype, rows, C, with_b1, strided):
+    """a = sigmoid(silu(h + b1) @ w2 + b2) and its backward (dh, db1, dw2, db2): one pass each instead of ATen's bias / SiLU /
+    Linear(C, 1) / Sigmoid chain (reference block/mamba_block.py:90-91)."""
+    from diffma_amd import hip_ops
+
+    if dtype == torch.float32 and C > 1024:
+        pytest.skip("fp32 rows hold at most 1024 values")
+    g = torch.Generator().manual_seed(rows + C)
+    wide = torch.randn(rows, C + (16 if strided else 0), generator=g).to(dtype)
+    h = wide[:, :C]
+    b1 = (torch.randn(C, generator=g) * 0.3) if with_b1 else None
+    w2 = torch.randn(C, generator=g) / C ** 0.5
+    b2 = torch.randn(1, generator=g) * 0.2
+    da = torch.randn(rows, 1, generator=g).to(dtype)
+    dev = lambda t: None if t is None else t.to(gpu)
+    hd = dev(wide)[:, :C]
+    assert hip_ops.gate_head_supported(hd)
+    a = hip_ops.gate_head_fwd(hd, dev(b1), dev(w2), dev(b2))
+    dh, db1, dw2, db2 = hip_ops.gate_head_bwd(dev(da), a, hd, dev(b1), dev(w2))
+    torch.cuda.synchronize()
+
+    h64 = h.double().requires_grad_(True)
+    b164 = None if b1 is None else b1.double().requires_grad_(True)
+    w264, b264 = w2.double().requires_grad_(True), b2.double().requires_grad_(True)
+    x = h64 if b164 is None else h64 + b164
+    ref = torch.sigmoid(torch.nn.functional.silu(x) @ w264[:, None] + b264)
+    ref.backward(da.double())
+    rtol, atol = TOL[dtype]
+    assert a.shape == (rows, 1) and a.dtype == dtype
+    torch.testing.assert_close(a.cpu().double(), ref.detach(), rtol=rtol, atol=atol)
+    # the kernel differentiates at ITS (rounded) output a; in 16-bit that rounding is the error floor of the gradients
+    gscale = float(h64.grad.abs().max()) + 1e-30
+    torch.testing.assert_close(dh.cpu().double(), h64.grad, rtol=rtol, atol=atol * gscale)
+    red = lambda got, want: torch.testing.assert_close(got.cpu().double().reshape(want.shape), want, rtol=max(rtol, 2e-3),
+                                                       atol=atol * (float(want.abs().max()) + 1e-30))
+    if b1 is not None:
+        red(db1, b164.grad)
+    red(dw2, w264.grad)
+    red(db2, b264.grad)
