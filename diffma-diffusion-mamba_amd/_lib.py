@@ -89,6 +89,7 @@ dm_conv_xproj_bwd_args = _make_struct("dm_conv_xproj_bwd_args")
 dm_merge_args = _make_struct("dm_merge_args")
 dm_gate_bwd_args = _make_struct("dm_gate_bwd_args")
 dm_dtproj_args = _make_struct("dm_dtproj_args")
+dm_dtproj_bwd_args = _make_struct("dm_dtproj_bwd_args")
 dm_ln_mod_args = _make_struct("dm_ln_mod_args")
 dm_blend_args = _make_struct("dm_blend_args")
 dm_gate_head_args = _make_struct("dm_gate_head_args")
@@ -136,7 +137,7 @@ def load():
                 fn.argtypes = [ctypes.c_int] * 4
             elif name == "dm_scan_bwd_launch_group_channels":
                 fn.argtypes = [ctypes.c_int] * 5
-            elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported"):
+            elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported", "dm_dtproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -167,3 +167,208 @@ extern "C" int dm_dtproj_softplus_fwd(const dm_dtproj_args* args, void* stream) 
     if (e != hipSuccess) { set_error("dm_dtproj_softplus_fwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// K8b  dm_dtproj_bwd -- both consumers of d(delta) in ONE read of it (round 3).
+//
+// The backward of delta_raw = x_dbl[:, :R] @ W^T needs   dxdt[m][r] = sum_d dd[m][d] * W[d][r]   (reduction over the channels) and
+// dW[d][r] = sum_m dd[m][d] * xdt[m][r]   (reduction over the rows).  As library GEMMs these are two passes over dd = d(delta_raw)
+// ([3*B*L, d_inner]: 616 MB at the bench shape -- 129 us + 112 us, plus a strided copy of the first product into its x_dbl columns
+// and the slab sum of the split-K second one).  Here a 512-thread workgroup walks 32-row tiles of dd; wave w owns the channels
+// [w*CH, (w+1)*CH), CH = dim / 8:
+//   * its 16-byte global loads of the tile ARE the MFMA fragments of the first product (K = channel is contiguous in memory);
+//     operands swapped (A = W, B = dd) so that an accumulator register quad is 4 consecutive r of one row: 8-byte stores;
+//     the 8 waves' partial [32 x R] tiles meet in LDS;
+//   * the same registers go to a row-major LDS image of the tile, and `ds_read_b64_tr_b16` hands them back with K = row
+//     (8 consecutive rows of one channel per lane): B fragments of  dW^T[r][d] += xdt^T[r][m] * dd[m][d]; the xdt tile takes the same
+//     route.  The accumulators (2 x CH/16 tiles) stay in registers for all tiles of the workgroup and leave as ONE partial
+//     [dim][R] fp32 image per workgroup (dm_colsum_f32 adds the images).
+// The next tile's global loads are issued before the current tile's products.  rows % 32 == 0, dim = 8 * CH with CH in {64, 96, 128},
+// rank in {16, 32} (dm_dtproj_bwd_supported); everything else keeps the two GEMMs.
+namespace dm {
+
+constexpr int DTB_WAVES = 8, DTB_TM = 32;
+
+template <typename T, int KC, int NR>      // KC = 32-channel chunks per wave (CH = 32 KC), NR = 16-wide r tiles (rank = 16 NR)
+__global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtproj_bwd_args p) {
+    constexpr int CH = 32 * KC, DIM = DTB_WAVES * CH, R = 16 * NR;
+    constexpr int LROW = DIM + 16;                 // elements; 32 bytes of padding: the 4 rows x 32 bytes of a transpose read fall on distinct banks
+    constexpr int XROW = R + 16;
+    __shared__ __attribute__((aligned(16))) T tile[DTB_TM][LROW];
+    __shared__ __attribute__((aligned(16))) T xt[DTB_TM][XROW];
+    __shared__ __attribute__((aligned(16))) float osum[DTB_WAVES][2 * NR][64][4];      // [wave][m-tile of rows x r tile][lane][4 consecutive r]
+    typedef short tr_v4s __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) tr_v4s* tr_ptr;
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, j = lane & 15;
+    const int d0 = wave * CH;
+    const T* __restrict__ DD = (const T*)p.ddelta;
+    const T* __restrict__ X = (const T*)p.xdbl;
+    const T* __restrict__ W = (const T*)p.w;
+    T* __restrict__ O = (T*)p.dxdbl;
+
+    // W fragments (operand A of product 1): lane (j, g) of tile (kc, nr) holds W[d0 + 32 kc + 8 g .. + 8][16 nr + j]
+    dtp_u32x4 wf[KC][NR];
+#pragma unroll
+    for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const T* src = W + (int64_t)(d0 + 32 * kc + 8 * g + 2 * e) * R + 16 * nr + j;
+                const uint32_t lo = __builtin_bit_cast(unsigned short, src[0]), hi = __builtin_bit_cast(unsigned short, src[R]);
+                w[e] = lo | (hi << 16);
+            }
+            wf[kc][nr] = (dtp_u32x4){w[0], w[1], w[2], w[3]};
+        }
+    }
+    f32x4 accw[NR][2 * KC];                        // dW^T tiles: rows = r (16 nr + 4 g + i), column = channel d0 + 16 nt + j
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int nt = 0; nt < 2 * KC; ++nt) accw[nr][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int ntile = p.rows / DTB_TM;
+    // fragments of a tile: [m-tile of 16 rows][kc]: lane (j, g) holds dd[tile*32 + 16 mt + j][d0 + 32 kc + 8 g .. + 8]
+    auto load_tile = [&](int t, dtp_u32x4(&f)[2][KC], dtp_u32x4& xv) {
+        t = (t < ntile) ? t : ntile - 1;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc)
+                f[mt][kc] = *reinterpret_cast<const dtp_u32x4*>(DD + (int64_t)(t * DTB_TM + 16 * mt + j) * DIM + d0 + 32 * kc + 8 * g);
+        // the xdt tile [32][R] is R/8 16-byte pieces per row: the first 32 * R / 8 threads of the workgroup fetch one each
+        const int pr = tid / (R / 8), pc = tid % (R / 8);
+        xv = (dtp_u32x4){0u, 0u, 0u, 0u};
+        if (pr < DTB_TM) xv = *reinterpret_cast<const dtp_u32x4*>(X + (int64_t)(t * DTB_TM + pr) * p.xd_sr + 8 * pc);
+    };
+    dtp_u32x4 cur[2][KC], nxt[2][KC], xcur, xnxt;
+    load_tile(blockIdx.x, cur, xcur);
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        load_tile(t + gridDim.x, nxt, xnxt);                       // lands while this tile is multiplied (clamped: always a legal tile)
+        // ---- product 1, this wave's channel slice: acc[mt][nr] = W-fragment x dd-fragment, D[r][row]
+        f32x4 acc1[2][NR];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kc = 0; kc < KC; ++kc) {
+                    if constexpr (std::is_same<T, bf16_t>::value)
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dtp_bf16x8, wf[kc][nr]), __builtin_bit_cast(dtp_bf16x8, cur[mt][kc]), a, 0, 0, 0);
+                    else
+                        a = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dtp_f16x8, wf[kc][nr]), __builtin_bit_cast(dtp_f16x8, cur[mt][kc]), a, 0, 0, 0);
+                }
+                acc1[mt][nr] = a;
+            }
+        // ---- stage: the tile row-major, the xdt tile, this wave's partial of product 1
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) *reinterpret_cast<dtp_u32x4*>(&tile[16 * mt + j][d0 + 32 * kc + 8 * g]) = cur[mt][kc];
+        {
+            const int pr = tid / (R / 8), pc = tid % (R / 8);
+            if (pr < DTB_TM) *reinterpret_cast<dtp_u32x4*>(&xt[pr][8 * pc]) = xcur;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) *reinterpret_cast<f32x4*>(&osum[wave][mt * NR + nr][lane][0]) = acc1[mt][nr];
+        __syncthreads();
+        // ---- product 1: sum the 8 waves' partials; thread (tile q, lane l) owns rows r = 16 nr + 4 (l >> 4) + 0..3 of output row 16 mt + (l & 15)
+        if (tid < 2 * NR * 64) {
+            const int q = tid >> 6, l = tid & 63;
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < DTB_WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&osum[w][q][l][0]);
+            const int mt = q / NR, nr = q % NR;
+            const u32x2_t pk = {dtp_mfma<T>::pack(s[0], s[1]), dtp_mfma<T>::pack(s[2], s[3])};
+            *reinterpret_cast<u32x2_t*>(O + (int64_t)(t * DTB_TM + 16 * mt + (l & 15)) * p.dxd_sr + 16 * nr + 4 * (l >> 4)) = pk;
+        }
+        // ---- product 2: dW^T[r][d] += xdt^T[r][m] * dd[m][d], K = the tile's 32 rows; both operands through transposing LDS reads:
+        //      lane (j, g) supplies the 8-byte piece (row 8 g + (j >> 2) [+ 4], columns c0 + 4 (j & 3) ..) and receives rows 8 g .. 8 g + 7 of column c0 + j
+        dtp_u32x4 xa[NR];
+#pragma unroll
+        for (int nr = 0; nr < NR; ++nr) {
+            const tr_v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)&xt[8 * g + (j >> 2)][16 * nr + 4 * (j & 3)]);
+            const tr_v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)&xt[8 * g + 4 + (j >> 2)][16 * nr + 4 * (j & 3)]);
+            const u32x2_t w0 = __builtin_bit_cast(u32x2_t, a0), w1 = __builtin_bit_cast(u32x2_t, a1);
+            xa[nr] = (dtp_u32x4){w0.x, w0.y, w1.x, w1.y};
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2 * KC; ++nt) {
+            const tr_v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)&tile[8 * g + (j >> 2)][d0 + 16 * nt + 4 * (j & 3)]);
+            const tr_v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_ptr)&tile[8 * g + 4 + (j >> 2)][d0 + 16 * nt + 4 * (j & 3)]);
+            const u32x2_t w0 = __builtin_bit_cast(u32x2_t, b0), w1 = __builtin_bit_cast(u32x2_t, b1);
+            const dtp_u32x4 bf = {w0.x, w0.y, w1.x, w1.y};
+#pragma unroll
+            for (int nr = 0; nr < NR; ++nr) {
+                if constexpr (std::is_same<T, bf16_t>::value)
+                    accw[nr][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dtp_bf16x8, xa[nr]), __builtin_bit_cast(dtp_bf16x8, bf), accw[nr][nt], 0, 0, 0);
+                else
+                    accw[nr][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(dtp_f16x8, xa[nr]), __builtin_bit_cast(dtp_f16x8, bf), accw[nr][nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                           // the images are rewritten by the next tile
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) cur[mt][kc] = nxt[mt][kc];
+        xcur = xnxt;
+    }
+    // ---- the workgroup's dW image [dim][R]: register i of lane (j, g) of tile (nr, nt) is dW[d0 + 16 nt + j][16 nr + 4 g + i]
+    float* part = p.part + (int64_t)blockIdx.x * DIM * R;
+#pragma unroll
+    for (int nr = 0; nr < NR; ++nr)
+#pragma unroll
+        for (int nt = 0; nt < 2 * KC; ++nt) *reinterpret_cast<f32x4*>(part + (int64_t)(d0 + 16 * nt + j) * R + 16 * nr + 4 * g) = accw[nr][nt];
+}
+
+template <typename T>
+static int dtproj_bwd_launch(const dm_dtproj_bwd_args& a, hipStream_t st) {
+    const dim3 grid((unsigned)a.nblk), block(64 * DTB_WAVES);
+    const int kc = a.dim / (32 * DTB_WAVES), nr = a.rank / 16;
+#define DM_DTB(KC, NR) hipLaunchKernelGGL((dtproj_bwd_kernel<T, KC, NR>), grid, block, 0, st, a)
+    switch (kc * 10 + nr) {
+        case 21: DM_DTB(2, 1); break;
+        case 22: DM_DTB(2, 2); break;
+        case 31: DM_DTB(3, 1); break;
+        case 32: DM_DTB(3, 2); break;
+        case 41: DM_DTB(4, 1); break;
+        case 42: DM_DTB(4, 2); break;
+        default: set_error("dm_dtproj_bwd: unsupported dim %d / rank %d", a.dim, a.rank); return DM_ERR_ARG;
+    }
+#undef DM_DTB
+    return DM_OK;
+}
+
+}  // namespace dm
+
+extern "C" int dm_dtproj_bwd_supported(int dim, int rank, int io_dtype) {
+    if (getenv("DIFFMA_DTPROJ_BWD_FUSED") && atoi(getenv("DIFFMA_DTPROJ_BWD_FUSED")) == 0) return 0;
+    return (io_dtype == DM_BF16 || io_dtype == DM_F16) && (rank == 16 || rank == 32) && (dim == 512 || dim == 768 || dim == 1024);
+}
+
+extern "C" int dm_dtproj_bwd(const dm_dtproj_bwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_dtproj_bwd: null args"); return DM_ERR_ARG; }
+    const dm_dtproj_bwd_args& a = *args;
+    if (!a.ddelta || !a.xdbl || !a.w || !a.dxdbl || !a.part) { set_error("dm_dtproj_bwd: null tensor pointer"); return DM_ERR_ARG; }
+    if (!dm_dtproj_bwd_supported(a.dim, a.rank, a.io_dtype)) { set_error("dm_dtproj_bwd: unsupported dim %d / rank %d / dtype %d", a.dim, a.rank, a.io_dtype); return DM_ERR_ARG; }
+    if (a.rows <= 0 || a.rows % DTB_TM != 0) { set_error("dm_dtproj_bwd: rows (%d) must be a positive multiple of %d", a.rows, DTB_TM); return DM_ERR_ARG; }
+    if (a.nblk <= 0 || a.nblk > a.rows / DTB_TM) { set_error("dm_dtproj_bwd: nblk (%d) must be in 1 .. rows / %d", a.nblk, DTB_TM); return DM_ERR_ARG; }
+    if (a.xd_sr % 8 != 0 || a.dxd_sr % 4 != 0 || ((uintptr_t)a.xdbl & 15) || ((uintptr_t)a.dxdbl & 7) || ((uintptr_t)a.ddelta & 15) || ((uintptr_t)a.part & 15)) {
+        set_error("dm_dtproj_bwd: xdbl rows must be 16-byte aligned (stride % 8), dxdbl rows 8-byte aligned (stride % 4)");
+        return DM_ERR_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = (a.io_dtype == DM_BF16) ? dtproj_bwd_launch<bf16_t>(a, st) : dtproj_bwd_launch<f16_t>(a, st);
+    if (rc != DM_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_dtproj_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}

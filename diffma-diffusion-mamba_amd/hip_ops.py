@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -621,6 +621,40 @@ def dtproj_softplus_fwd(xdbl, w, bias):
     es = xdbl.element_size()
     _launch("dm_dtproj_softplus_fwd", a, xdbl, M * (Dm + R) * es + Dm * R * es + 4 * Dm)
     return delta
+
+
+DTPROJ_BWD_BLOCKS = 256              # workgroups (= partial dW images) of dm_dtproj_bwd: one per CU
+
+
+def dtproj_bwd_supported(ddelta, xdbl, w, dxdbl):
+    """ddelta [M, Dm] contiguous, xdbl / dxdbl [M, >= R] row-major views (16-bit), w [Dm, R]."""
+    if not (DTPROJ_FUSED and ddelta.is_cuda and ddelta.dtype in (torch.bfloat16, torch.float16) and w.dtype == ddelta.dtype
+            and xdbl.dtype == ddelta.dtype and dxdbl.dtype == ddelta.dtype):
+        return False
+    M = ddelta.shape[0]
+    if M % 32 or not ddelta.is_contiguous() or ddelta.data_ptr() % 16:
+        return False
+    if xdbl.stride(-1) != 1 or xdbl.stride(0) % 8 or xdbl.data_ptr() % 16 or dxdbl.stride(-1) != 1 or dxdbl.stride(0) % 4 or dxdbl.data_ptr() % 8:
+        return False
+    return bool(_lib.load().dm_dtproj_bwd_supported(int(w.shape[0]), int(w.shape[1]), dtype_code(ddelta)))
+
+
+def dtproj_bwd(ddelta, xdbl, w, dxdbl):
+    """One read of ddelta [M, Dm]: dxdbl[:, :R] = ddelta @ w (written in place into the given rows) and returns
+    dW [Dm, R] fp32 = ddelta^T @ xdbl[:, :R]."""
+    _require_gpu(ddelta, xdbl, w, dxdbl)
+    M, Dm = ddelta.shape
+    R = w.shape[1]
+    w = w.contiguous()
+    nblk = max(1, min(DTPROJ_BWD_BLOCKS, M // 32))
+    part = torch.empty((nblk, Dm * R), dtype=torch.float32, device=ddelta.device)
+    a = dm_dtproj_bwd_args()
+    a.rows, a.dim, a.rank, a.io_dtype, a.nblk = M, Dm, R, dtype_code(ddelta), nblk
+    a.ddelta, a.xdbl, a.w, a.dxdbl, a.part = _ptr(ddelta), _ptr(xdbl), _ptr(w), _ptr(dxdbl), _ptr(part)
+    a.xd_sr, a.dxd_sr = xdbl.stride(0), dxdbl.stride(0)
+    es = ddelta.element_size()
+    _launch("dm_dtproj_bwd", a, ddelta, M * (Dm + 2 * R) * es + Dm * R * (es + 4))
+    return colsum(part).view(Dm, R)
 
 
 LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK

@@ -325,8 +325,12 @@ class _SpiralSSMFn(torch.autograd.Function):
                 out_row_index=oidx, batch_per_dir=Bsz, dout_per_seq=not ctx.merge,
                 dbc_out=dx_dbl.view(ndir * Bsz, L, R + 2 * N)[..., R:])      # dB | dC land in their x_dbl columns
         ddelta2 = ddelta.view(M, Din)
-        dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)            # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
-        dWdt = _tn_splitk(ddelta2, x_dbl[:, :R]).to(Wdt.dtype)                   # [Din, R]; the dt columns of x_dbl in place (leading dimension R + 2N)
+        if hip_ops.dtproj_bwd_supported(ddelta2, x_dbl, Wdt_c, dx_dbl):
+            # both consumers of ddelta -- the dt columns of d(x_dbl) and dW_dt -- in ONE read of it (csrc/dtproj.hip, K8b)
+            dWdt = hip_ops.dtproj_bwd(ddelta2, x_dbl, Wdt_c, dx_dbl).to(Wdt.dtype)
+        else:
+            dx_dbl[:, :R] = GemmChain.run(torch.mm, ddelta2, Wdt_c)        # (a strided `out=` is an untuned GEMM shape class: pathologically slow by default)
+            dWdt = _tn_splitk(ddelta2, x_dbl[:, :R]).to(Wdt.dtype)               # [Din, R]; the dt columns of x_dbl in place (leading dimension R + 2N)
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz, conv_w.shape[-1], du, dx_dbl):
             # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]

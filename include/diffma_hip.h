@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 23
+#define DM_ABI_VERSION 24
 
 typedef enum {
     DM_OK = 0,
@@ -353,6 +353,26 @@ typedef struct {
 
 int dm_dtproj_softplus_fwd(const dm_dtproj_args *args, void *stream);
 int dm_dtproj_softplus_supported(int dim, int rank, int io_dtype);
+
+/* Backward of the product above (the softplus' derivative is applied by dm_selective_scan_bwd, DM_FLAG_DELTA_ACTIVATED):
+ *     dxdbl[m][r]  = sum_d ddelta[m][d] * w[d][r]      r < rank   (written into the first `rank` columns of the d x_dbl rows)
+ *     part[blk]    = this workgroup's share of  dW[d][r] = sum_m ddelta[m][d] * xdbl[m][r]   ([nblk][dim][rank] fp32; dm_colsum_f32)
+ * in ONE read of ddelta (block/mamba.py:346-348 differentiates this product inside mamba_inner_fn's backward).  rows % 32 == 0,
+ * nblk in 1 .. rows / 32 (the grid), dims as dm_dtproj_bwd_supported says (16-bit I/O, dim in {512, 768, 1024}, rank in {16, 32}). */
+typedef struct {
+    int32_t rows, dim, rank;
+    int32_t io_dtype;
+    int32_t nblk, _pad;
+    const void *ddelta;        /* [rows][dim] contiguous, 16-byte aligned                                           */
+    const void *xdbl;          /* [rows][>= rank], row stride xd_sr elements (a multiple of 8), 16-byte aligned     */
+    const void *w;             /* [dim][rank] contiguous                                                            */
+    void *dxdbl;               /* [rows][>= rank], row stride dxd_sr elements (a multiple of 4), 8-byte aligned     */
+    float *part;               /* [nblk][dim][rank]                                                                 */
+    int64_t xd_sr, dxd_sr;
+} dm_dtproj_bwd_args;
+
+int dm_dtproj_bwd(const dm_dtproj_bwd_args *args, void *stream);
+int dm_dtproj_bwd_supported(int dim, int rank, int io_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * Block elementwise ops of Spiral_MambaBlock.forward (reference block/mamba_block.py:100-115), each one

@@ -1056,3 +1056,41 @@ def test_gate_head_matches_torch(gpu, dtype, rows, C, with_b1, strided):
         red(db1, b164.grad)
     red(dw2, w264.grad)
     red(db2, b264.grad)
+
+
+# ---- backward of the dt_proj product: both consumers of d(delta) in one pass (csrc/dtproj.hip, K8b) -------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,Dm,R,N", [(3 * 8 * 196, 1024, 32, 16), (64, 512, 16, 16), (32 * 37, 768, 32, 16), (32, 1024, 16, 8), (9408, 1024, 32, 16)])
+def test_dtproj_bwd_matches_torch(gpu, dtype, M, Dm, R, N):
+    """dx_dbl[:, :R] = ddelta @ W and dW = ddelta^T @ x_dbl[:, :R] from ONE read of ddelta; the other columns of d(x_dbl) (dB | dC,
+    written by the scan backward) must stay untouched."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(M + Dm + R)
+    ddelta = (torch.randn(M, Dm, generator=g) * 0.5).to(dtype)
+    xdbl = torch.randn(M, R + 2 * N, generator=g).to(dtype)
+    w = (torch.randn(Dm, R, generator=g) / Dm ** 0.5).to(dtype)
+    dxdbl = torch.full((M, R + 2 * N), 7.0).to(dtype)
+    dd, xd, wd, dxd = ddelta.to(gpu), xdbl.to(gpu), w.to(gpu), dxdbl.to(gpu)
+    assert hip_ops.dtproj_bwd_supported(dd, xd, wd, dxd)
+    dW = hip_ops.dtproj_bwd(dd, xd, wd, dxd)
+    torch.cuda.synchronize()
+    ref_dx = ddelta.double() @ w.double()
+    ref_dW = ddelta.double().t() @ xdbl[:, :R].double()
+    rtol, atol = TOL[dtype]
+    torch.testing.assert_close(dxd[:, :R].cpu().double(), ref_dx, rtol=rtol, atol=atol * float(ref_dx.abs().max()))
+    assert bool((dxd[:, R:] == 7.0).all())
+    assert dW.shape == (Dm, R) and dW.dtype == torch.float32
+    torch.testing.assert_close(dW.cpu().double(), ref_dW, rtol=1e-4, atol=1e-5 * float(ref_dW.abs().max()) * max(1.0, M / 1000))
+
+
+def test_dtproj_bwd_unsupported_shapes_fall_back(gpu):
+    from diffma_amd import hip_ops
+
+    mk = lambda *s, dt=torch.bfloat16: torch.zeros(*s, dtype=dt, device=gpu)
+    assert not hip_ops.dtproj_bwd_supported(mk(48, 1024), mk(48, 64), mk(1024, 32), mk(48, 64))              # rows % 32
+    assert not hip_ops.dtproj_bwd_supported(mk(64, 1536), mk(64, 64), mk(1536, 32), mk(64, 64))              # width not instantiated
+    assert not hip_ops.dtproj_bwd_supported(mk(64, 1024, dt=torch.float32), mk(64, 64, dt=torch.float32), mk(1024, 32, dt=torch.float32),
+                                            mk(64, 64, dt=torch.float32))
+    with pytest.raises(Exception):
+        hip_ops.dtproj_bwd(mk(48, 1024), mk(48, 64), mk(1024, 32), mk(48, 64))
