@@ -384,8 +384,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // u / delta / dout (/ z) values and the checkpoint of sub-chunk ci-1 are already in flight into their own registers -- RAW
     // words, converted only when ci-1 starts, so that no wait lands behind the loads -- and the row-table entries of sub-chunk
     // ci-2 into SGPRs.  Until round 3 a chunk's 24 input loads were issued at its top and consumed at once: every wave spent one
-    // full memory latency per 8 steps in s_waitcnt (SQ_WAIT_INST_ANY = 27 % of the wave cycles, the VALU 71 % busy at two waves
-    // per SIMD).  Registers: 12 converted + 12 raw inputs (24 converted before), 3 checkpoint slices (end state | current | next;
+    // full memory latency per 8 steps in s_waitcnt (SQ_WAIT_ANY = 24 % of the wave cycles, the VALU 71 % busy at two waves
+    // per SIMD; 15 % and 78 % with the pipeline).  Registers: 12 converted + 12 raw inputs (24 converted before), 3 checkpoint slices (end state | current | next;
     // 5 before with the chunk-level checkpoint prefetch).
     static_assert(SUB == 4, "row-table entries of a sub-chunk travel as one 4-dword scalar load");
     constexpr int NSC = CK / SUB;
