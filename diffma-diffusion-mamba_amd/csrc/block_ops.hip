@@ -8,6 +8,7 @@
 // per-channel (dgamma, dbeta) sums leave the kernel as one fp32 partial row per block (no atomics); the
 // caller adds the handful of partial rows.
 #include "dm_common.h"
+#include <type_traits>
 
 namespace dm {
 
@@ -118,8 +119,14 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_fwd_kernel(const dm_ln_m
     }
 }
 
+// TM = no_mod_t: the launch has neither shift / scale nor a mask (the LayerNorm of the fusion MLP's concatenated input): the
+// modulation's registers (scale row, dshift / dscale accumulators: 48 VGPRs at C = 1024) are compiled out -- 202 -> <= 168 VGPRs, a
+// third wave per SIMD for a kernel that is a chain of dependent row passes.
+struct no_mod_t {};
 template <typename TX, typename TY, typename TM, int VEC, int NIT>
 __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_mod_args p) {
+    constexpr bool MOD = !std::is_same<TM, no_mod_t>::value;
+    typedef typename std::conditional<MOD, TM, float>::type TMl;      // the type the (compiled-out) modulation loads are written with
     __shared__ float lds[LN_WAVES][64 * NIT * VEC];            // one of the 4 partial-sum rows at a time (64 KB for all four
                                                                 // at once capped the occupancy of this HBM-bound kernel at 2 WGs/CU)
     const int lane = threadIdx.x & 63;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
         if (c < C) {
             if (p.gamma) ld_vec<float, VEC>(g[it], p.gamma + c);
             if (p.beta) ld_vec<float, VEC>(be[it], p.beta + c);
-            if (p.scale) ld_vec<TM, VEC>(sc[it], (const TM*)p.scale + (int64_t)b * p.mod_sb + c);
+            if constexpr (MOD) { if (p.scale) ld_vec<TMl, VEC>(sc[it], (const TMl*)p.scale + (int64_t)b * p.mod_sb + c); }
         }
     }
     // The gradient that is ADDED to dx (dx_add: the read-only second gradient of x; accumulate: what dx / dx2 already hold) is
@@ -150,7 +157,8 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
     for (int lr = row0 + wave; lr < row1; lr += LN_WAVES) {
         const int64_t r = (int64_t)b * p.rows_per_batch + lr;
         const float mean = p.stats[2 * r], rstd = p.stats[2 * r + 1];
-        const float mk = p.mask ? io<TM>::ld((const TM*)p.mask + r) : 1.f;
+        float mk = 1.f;
+        if constexpr (MOD) { if (p.mask) mk = io<TMl>::ld((const TMl*)p.mask + r); }
         float xh[NIT][VEC], dxh[NIT][VEC], old[NIT][VEC];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -160,7 +168,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
                 float xv[VEC], d1[VEC], d2[VEC];
                 ld_vec<TX, VEC>(xv, row_src((const TX*)p.x, (const TX*)p.x2, r, p.x_sr, p.x2_sr, p.C1, c));
                 ld_vec<TY, VEC>(d1, (const TY*)p.dy1 + r * p.y_sr + c);
-                if (p.dy2) ld_vec<TY, VEC>(d2, (const TY*)p.dy2 + r * p.y_sr + c);
+                if constexpr (MOD) { if (p.dy2) ld_vec<TY, VEC>(d2, (const TY*)p.dy2 + r * p.y_sr + c); }
                 if (has_old) {
                     const TX* src = p.dx_add ? (const TX*)p.dx_add + r * p.dxa_sr + c
                                              : ((c < p.C1) ? (const TX*)p.dx + r * p.dx_sr + c : (const TX*)p.dx2 + r * p.dx2_sr + (c - p.C1));
@@ -169,11 +177,14 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
 #pragma unroll
                 for (int j = 0; j < VEC; ++j) {
                     xh[it][j] = (xv[j] - mean) * rstd;
-                    const float gm = p.dy2 ? d1[j] + d2[j] * mk : d1[j];
-                    const float n = xh[it][j] * g[it][j] + be[it][j];
-                    a_sh[it][j] += gm;
-                    a_sc[it][j] += gm * n;
-                    const float gn = gm * (1.f + sc[it][j]);
+                    float gm = d1[j], gn = d1[j];
+                    if constexpr (MOD) {
+                        if (p.dy2) gm = d1[j] + d2[j] * mk;
+                        const float n = xh[it][j] * g[it][j] + be[it][j];
+                        a_sh[it][j] += gm;
+                        a_sc[it][j] += gm * n;
+                        gn = gm * (1.f + sc[it][j]);
+                    }
                     a_g[it][j] += gn * xh[it][j];
                     a_b[it][j] += gn;
                     dxh[it][j] = gn * g[it][j];
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
                 const int c = (it * 64 + lane) * VEC + j;
-                lds[wave][c] = (k == 0) ? a_sh[it][j] : (k == 1) ? a_sc[it][j] : (k == 2) ? a_g[it][j] : a_b[it][j];
+                lds[wave][c] = (k == 0) ? (MOD ? a_sh[it][j] : 0.f) : (k == 1) ? (MOD ? a_sc[it][j] : 0.f) : (k == 2) ? a_g[it][j] : a_b[it][j];
             }
         }
         __syncthreads();
@@ -362,6 +373,8 @@ static int ln_launch(const dm_ln_mod_args& a, hipStream_t st, bool bwd) {
     }
     const int bpb = (a.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
     dim3 grid((unsigned)(a.batch * bpb));
+    if (!a.scale && !a.mask && !a.dy2)
+        return pick_shape(C, vec_ok, DM_SHAPE_SWITCH(ln_mod_bwd_kernel, TX DM_COMMA TY DM_COMMA no_mod_t, grid, a), "dm_ln_mod_bwd");
     return pick_shape(C, vec_ok, DM_SHAPE_SWITCH(ln_mod_bwd_kernel, TX DM_COMMA TY DM_COMMA TM, grid, a), "dm_ln_mod_bwd");
 }
 

@@ -981,3 +981,53 @@ def test_step_prep_is_bitwise_neutral(gpu, monkeypatch):
     fresh = torch.nn.Parameter(torch.ones(4, 4, device=gpu))
     step_prep._SHADOWS[id(fresh)] = (weakref.ref(dead), torch.zeros(4, 4, device=gpu, dtype=torch.bfloat16), fresh._version)
     assert step_prep.shadow_of(fresh, torch.bfloat16) is None and id(fresh) not in step_prep._SHADOWS
+
+
+def test_full_width_mixer_takes_the_fused_dtproj_backward(gpu, monkeypatch):
+    """At DiffMa's real mixer width (d_model 512 -> d_inner 1024, dt_rank 32) with rows % 32 == 0 the backward's two dt_proj products come
+    from dm_dtproj_bwd (K8b, one read of d delta); every gradient against fp64 autograd through the oracle, and equal (to bf16 rounding)
+    to the two-GEMM form (DIFFMA_DTPROJ_BWD_FUSED=0, read by the library at call time)."""
+    from diffma_amd import hip_ops
+    from diffma_amd.mamba import Mamba
+    from diffma_amd.tools import spiral
+    from oracle.mamba_ref import mamba_spiral_forward_ref
+
+    calls = {"dtproj_bwd": 0}
+    real = hip_ops.dtproj_bwd
+    monkeypatch.setattr(hip_ops, "dtproj_bwd", lambda *a, **k: (calls.__setitem__("dtproj_bwd", calls["dtproj_bwd"] + 1), real(*a, **k))[1])
+    torch.manual_seed(3)
+    n, B, d_model = 4, 8, 512                                       # 3 directions x 8 x 16 tokens = 384 rows
+    orders, inverses = spiral(n)
+    lists = (orders[2], orders[3], inverses[2], inverses[3])
+    mix = Mamba(d_model=d_model, d_state=16, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+                origina_list_reversal=lists[3]).to(gpu)
+    x0 = torch.randn(B, n * n, d_model, device=gpu)
+    dy = torch.randn(B, n * n, d_model, device=gpu)
+
+    def run():
+        for p in mix.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = mix(x, "spiral")
+        (y.float() * dy).sum().backward()
+        return y.detach().float(), x.grad.clone(), {k: p.grad.clone() for k, p in mix.named_parameters()}
+
+    y1, dx1, g1 = run()
+    assert calls["dtproj_bwd"] == 1, calls
+    monkeypatch.setenv("DIFFMA_DTPROJ_BWD_FUSED", "0")
+    y0, dx0, g0 = run()
+    assert calls["dtproj_bwd"] == 1, calls                        # the predicate said no: the two GEMMs ran
+    monkeypatch.delenv("DIFFMA_DTPROJ_BWD_FUSED")
+    assert torch.equal(y0, y1)
+    assert rel_l2(dx1.cpu(), dx0.cpu()) <= 1e-2
+    for k in g1:
+        assert rel_l2(g1[k].cpu(), g0[k].cpu()) <= 1e-2, (k, rel_l2(g1[k].cpu(), g0[k].cpu()))
+    params = {k: v.detach().cpu().double().requires_grad_(True) for k, v in mix.state_dict().items()}
+    x64 = x0.cpu().double().requires_grad_(True)
+    yr = mamba_spiral_forward_ref(x64, params, lists, dtype=torch.float64)
+    (yr * dy.cpu().double()).sum().backward()
+    assert rel_l2(y1.cpu(), yr.detach()) <= 2e-2
+    assert rel_l2(dx1.cpu(), x64.grad) <= 6e-2
+    for k, g in g1.items():
+        assert rel_l2(g.cpu(), params[k].grad) <= 6e-2, (k, rel_l2(g.cpu(), params[k].grad))
