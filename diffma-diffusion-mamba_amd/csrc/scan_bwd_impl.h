@@ -316,6 +316,31 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // and store its dB/dC partial rows
     auto flush_dbc = [&](int chunk) {
         const int l0 = chunk * CK;
+        if constexpr (MFMA_RED && !TRRED && SPLIT == 1 && N == 16) {
+            // 16-byte reads: a thread owns a QUAD of outputs (4 consecutive registers of a lane slot are 4 consecutive values) and a
+            // quarter of the 16 row positions; the four quarter-owners are neighbouring lanes and meet through two quad-permute adds.
+            // 16 ds_read_b128 per thread and chunk instead of 64 ds_read_b32 (8 -> 2 LDS instructions per step; the dword form also ran
+            // a 2-way bank conflict between the wave's two steps).
+            static_assert(CK * 2 * N == 64 * BWD_WAVES, "one output per thread");
+            const int tq = tid & 3, g4 = (tid >> 2) & 7, j = tid >> 5;
+            const float* base = &red_lds[0][j][(g4 >> 2) * RED_HALF + (16 * (g4 & 3) + 4 * tq) * 4 + (g4 & 3) * 8];
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < BWD_WAVES; ++w)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc4 += *reinterpret_cast<const f32x4*>(base + w * (CK * RED_ROW) + t * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = acc4[i];
+                v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+                v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+                acc4[i] = v;
+            }
+            const float mine = tq == 0 ? acc4[0] : (tq == 1 ? acc4[1] : (tq == 2 ? acc4[2] : acc4[3]));             // output 4 g4 + tq of step j
+            const int vo_p = (l0 + j < L) ? (((l0 + j) * nwg + (int)blockIdx.x) * (2 * N) + 4 * g4 + tq) * 4 : BIO_OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine), r_dbc, vo_p, 0, 0);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < BC_PER_THREAD; ++it) {
             const int e_ = tid + it * 64 * BWD_WAVES;
