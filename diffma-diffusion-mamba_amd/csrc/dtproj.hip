@@ -183,7 +183,8 @@ extern "C" int dm_dtproj_softplus_fwd(const dm_dtproj_args* args, void* stream) 
 //     (8 consecutive rows of one channel per lane): B fragments of  dW^T[r][d] += xdt^T[r][m] * dd[m][d]; the xdt tile takes the same
 //     route.  The accumulators (2 x CH/16 tiles) stay in registers for all tiles of the workgroup and leave as ONE partial
 //     [dim][R] fp32 image per workgroup (dm_colsum_f32 adds the images).
-// The next tile's global loads are issued before the current tile's products.  rows % 32 == 0, dim = 8 * CH with CH in {64, 96, 128},
+// The next tile's global loads are issued before the current tile's products.  Any row count (a ragged last tile reads row rows-1 for
+// the missing rows and zeroes them at use), dim = 8 * CH with CH in {64, 96, 128},
 // rank in {16, 32} (dm_dtproj_bwd_supported); everything else keeps the two GEMMs.
 namespace dm {
 
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtp
 #pragma unroll
         for (int nt = 0; nt < 2 * KC; ++nt) accw[nr][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int ntile = p.rows / DTB_TM;
+    const int ntile = (p.rows + DTB_TM - 1) / DTB_TM;             // the last tile may be ragged: its rows past the end read row rows-1 and are zeroed at use
     // fragments of a tile: [m-tile of 16 rows][kc]: lane (j, g) holds dd[tile*32 + 16 mt + j][d0 + 32 kc + 8 g .. + 8]
     auto load_tile = [&](int t, dtp_u32x4(&f)[2][KC], dtp_u32x4& xv) {
         t = (t < ntile) ? t : ntile - 1;
@@ -239,16 +240,24 @@ __global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtp
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int kc = 0; kc < KC; ++kc)
-                f[mt][kc] = *reinterpret_cast<const dtp_u32x4*>(DD + (int64_t)(t * DTB_TM + 16 * mt + j) * DIM + d0 + 32 * kc + 8 * g);
+                f[mt][kc] = *reinterpret_cast<const dtp_u32x4*>(DD + (int64_t)min(t * DTB_TM + 16 * mt + j, p.rows - 1) * DIM + d0 + 32 * kc + 8 * g);
         // the xdt tile [32][R] is R/8 16-byte pieces per row: the first 32 * R / 8 threads of the workgroup fetch one each
         const int pr = tid / (R / 8), pc = tid % (R / 8);
         xv = (dtp_u32x4){0u, 0u, 0u, 0u};
-        if (pr < DTB_TM) xv = *reinterpret_cast<const dtp_u32x4*>(X + (int64_t)(t * DTB_TM + pr) * p.xd_sr + 8 * pc);
+        if (pr < DTB_TM) xv = *reinterpret_cast<const dtp_u32x4*>(X + (int64_t)min(t * DTB_TM + pr, p.rows - 1) * p.xd_sr + 8 * pc);
     };
     dtp_u32x4 cur[2][KC], nxt[2][KC], xcur, xnxt;
     load_tile(blockIdx.x, cur, xcur);
     for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
         load_tile(t + gridDim.x, nxt, xnxt);                       // lands while this tile is multiplied (clamped: always a legal tile)
+        if (t == ntile - 1 && p.rows % DTB_TM != 0) {              // ragged last tile (wave-uniform): rows past the end contribute nothing
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                if (t * DTB_TM + 16 * mt + j >= p.rows) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; ++kc) cur[mt][kc] = (dtp_u32x4){0u, 0u, 0u, 0u};
+                }
+        }
         // ---- product 1, this wave's channel slice: acc[mt][nr] = W-fragment x dd-fragment, D[r][row]
         f32x4 acc1[2][NR];
 #pragma unroll
@@ -287,7 +296,8 @@ __global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtp
             for (int w = 0; w < DTB_WAVES; ++w) s += *reinterpret_cast<const f32x4*>(&osum[w][q][l][0]);
             const int mt = q / NR, nr = q % NR;
             const u32x2_t pk = {dtp_mfma<T>::pack(s[0], s[1]), dtp_mfma<T>::pack(s[2], s[3])};
-            *reinterpret_cast<u32x2_t*>(O + (int64_t)(t * DTB_TM + 16 * mt + (l & 15)) * p.dxd_sr + 16 * nr + 4 * (l >> 4)) = pk;
+            const int orow = t * DTB_TM + 16 * mt + (l & 15);
+            if (orow < p.rows) *reinterpret_cast<u32x2_t*>(O + (int64_t)orow * p.dxd_sr + 16 * nr + 4 * (l >> 4)) = pk;
         }
         // ---- product 2: dW^T[r][d] += xdt^T[r][m] * dd[m][d], K = the tile's 32 rows; both operands through transposing LDS reads:
         //      lane (j, g) supplies the 8-byte piece (row 8 g + (j >> 2) [+ 4], columns c0 + 4 (j & 3) ..) and receives rows 8 g .. 8 g + 7 of column c0 + j
@@ -359,8 +369,8 @@ extern "C" int dm_dtproj_bwd(const dm_dtproj_bwd_args* args, void* stream) {
     const dm_dtproj_bwd_args& a = *args;
     if (!a.ddelta || !a.xdbl || !a.w || !a.dxdbl || !a.part) { set_error("dm_dtproj_bwd: null tensor pointer"); return DM_ERR_ARG; }
     if (!dm_dtproj_bwd_supported(a.dim, a.rank, a.io_dtype)) { set_error("dm_dtproj_bwd: unsupported dim %d / rank %d / dtype %d", a.dim, a.rank, a.io_dtype); return DM_ERR_ARG; }
-    if (a.rows <= 0 || a.rows % DTB_TM != 0) { set_error("dm_dtproj_bwd: rows (%d) must be a positive multiple of %d", a.rows, DTB_TM); return DM_ERR_ARG; }
-    if (a.nblk <= 0 || a.nblk > a.rows / DTB_TM) { set_error("dm_dtproj_bwd: nblk (%d) must be in 1 .. rows / %d", a.nblk, DTB_TM); return DM_ERR_ARG; }
+    if (a.rows <= 0) { set_error("dm_dtproj_bwd: rows (%d) must be positive", a.rows); return DM_ERR_ARG; }
+    if (a.nblk <= 0 || a.nblk > (a.rows + DTB_TM - 1) / DTB_TM) { set_error("dm_dtproj_bwd: nblk (%d) must be in 1 .. ceil(rows / %d)", a.nblk, DTB_TM); return DM_ERR_ARG; }
     if (a.xd_sr % 8 != 0 || a.dxd_sr % 4 != 0 || ((uintptr_t)a.xdbl & 15) || ((uintptr_t)a.dxdbl & 7) || ((uintptr_t)a.ddelta & 15) || ((uintptr_t)a.part & 15)) {
         set_error("dm_dtproj_bwd: xdbl rows must be 16-byte aligned (stride % 8), dxdbl rows 8-byte aligned (stride % 4)");
         return DM_ERR_ARG;

@@ -631,8 +631,7 @@ def dtproj_bwd_supported(ddelta, xdbl, w, dxdbl):
     if not (DTPROJ_FUSED and ddelta.is_cuda and ddelta.dtype in (torch.bfloat16, torch.float16) and w.dtype == ddelta.dtype
             and xdbl.dtype == ddelta.dtype and dxdbl.dtype == ddelta.dtype):
         return False
-    M = ddelta.shape[0]
-    if M % 32 or not ddelta.is_contiguous() or ddelta.data_ptr() % 16:
+    if ddelta.shape[0] < 1 or not ddelta.is_contiguous() or ddelta.data_ptr() % 16:
         return False
     if xdbl.stride(-1) != 1 or xdbl.stride(0) % 8 or xdbl.data_ptr() % 16 or dxdbl.stride(-1) != 1 or dxdbl.stride(0) % 4 or dxdbl.data_ptr() % 8:
         return False
@@ -646,7 +645,7 @@ def dtproj_bwd(ddelta, xdbl, w, dxdbl):
     M, Dm = ddelta.shape
     R = w.shape[1]
     w = w.contiguous()
-    nblk = max(1, min(DTPROJ_BWD_BLOCKS, M // 32))
+    nblk = max(1, min(DTPROJ_BWD_BLOCKS, (M + 31) // 32))
     part = torch.empty((nblk, Dm * R), dtype=torch.float32, device=ddelta.device)
     a = dm_dtproj_bwd_args()
     a.rows, a.dim, a.rank, a.io_dtype, a.nblk = M, Dm, R, dtype_code(ddelta), nblk

@@ -357,8 +357,8 @@ int dm_dtproj_softplus_supported(int dim, int rank, int io_dtype);
 /* Backward of the product above (the softplus' derivative is applied by dm_selective_scan_bwd, DM_FLAG_DELTA_ACTIVATED):
  *     dxdbl[m][r]  = sum_d ddelta[m][d] * w[d][r]      r < rank   (written into the first `rank` columns of the d x_dbl rows)
  *     part[blk]    = this workgroup's share of  dW[d][r] = sum_m ddelta[m][d] * xdbl[m][r]   ([nblk][dim][rank] fp32; dm_colsum_f32)
- * in ONE read of ddelta (block/mamba.py:346-348 differentiates this product inside mamba_inner_fn's backward).  rows % 32 == 0,
- * nblk in 1 .. rows / 32 (the grid), dims as dm_dtproj_bwd_supported says (16-bit I/O, dim in {512, 768, 1024}, rank in {16, 32}). */
+ * in ONE read of ddelta (block/mamba.py:346-348 differentiates this product inside mamba_inner_fn's backward).  Any row count,
+ * nblk in 1 .. ceil(rows / 32) (the grid), dims as dm_dtproj_bwd_supported says (16-bit I/O, dim in {512, 768, 1024}, rank in {16, 32}). */
 typedef struct {
     int32_t rows, dim, rank;
     int32_t io_dtype;

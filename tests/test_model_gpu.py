@@ -984,7 +984,7 @@ def test_step_prep_is_bitwise_neutral(gpu, monkeypatch):
 
 
 def test_full_width_mixer_takes_the_fused_dtproj_backward(gpu, monkeypatch):
-    """At DiffMa's real mixer width (d_model 512 -> d_inner 1024, dt_rank 32) with rows % 32 == 0 the backward's two dt_proj products come
+    """At DiffMa's real mixer width (d_model 512 -> d_inner 1024, dt_rank 32) the backward's two dt_proj products come
     from dm_dtproj_bwd (K8b, one read of d delta); every gradient against fp64 autograd through the oracle, and equal (to bf16 rounding)
     to the two-GEMM form (DIFFMA_DTPROJ_BWD_FUSED=0, read by the library at call time)."""
     from diffma_amd import hip_ops
