@@ -169,6 +169,25 @@ def _tn_splitk(a, b):
     return GemmChain.run(_tn_splitk_impl, a, b)
 
 
+_MM_F32 = [None]          # does torch.mm take out_dtype on this device?  (aten::mm.dtype: 16-bit operands, fp32 result, one launch)
+
+
+def _mm_f32(x, y):
+    """x @ y in fp32 from 16-bit operands WITHOUT a separate cast launch where the library offers it (hipBLASLt accumulates in fp32
+    anyway; the 16-bit result + `.float()` of the plain form rounds the weight gradient once more and costs a launch per GEMM -- ~150 per
+    training step, which is what a small-batch step is made of)."""
+    if x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and _MM_F32[0] is not False and os.environ.get("DIFFMA_MM_F32", "1") == "1":
+        try:
+            out = torch.mm(x, y, out_dtype=torch.float32)
+            _MM_F32[0] = True
+            return out
+        except (RuntimeError, NotImplementedError, TypeError):
+            if _MM_F32[0]:                       # it worked before: a real error, not a missing feature
+                raise
+            _MM_F32[0] = False
+    return (x @ y).float()
+
+
 def _tn_splitk_impl(a, b):
     """a^T @ b for tall operands a (M, P), b (M, Q): the reduction runs over M = B*L or ndir*B*L (50 176 /
     150 528 at the bench shape), which hipBLASLt does not split -- a single-pass GEMM is 2-8x off its memory
@@ -184,7 +203,7 @@ def _tn_splitk_impl(a, b):
     for C in (64, 32, 16, 8):
         if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23) and a.stride(1) == 1 and b.stride(1) == 1:
             return torch.bmm(slabs(a, C).transpose(1, 2), slabs(b, C)).sum(0, dtype=torch.float32)      # the cast is fused into the reduction
-    return (a.t() @ b).float()
+    return _mm_f32(a.t(), b)
 
 
 class _LinearSplitKFn(torch.autograd.Function):

@@ -1031,3 +1031,19 @@ def test_full_width_mixer_takes_the_fused_dtproj_backward(gpu, monkeypatch):
     assert rel_l2(dx1.cpu(), x64.grad) <= 6e-2
     for k, g in g1.items():
         assert rel_l2(g.cpu(), params[k].grad) <= 6e-2, (k, rel_l2(g.cpu(), params[k].grad))
+
+
+def test_small_batch_weight_gradient_gemm_writes_fp32(gpu):
+    """Below the split-K threshold the weight-gradient product a^T b leaves the GEMM in fp32 (aten::mm.dtype) instead of as a 16-bit
+    result + cast launch: fp32 result, at least as close to the fp64 product as the rounded form."""
+    from diffma_amd import selective_scan_interface as ssi
+
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(1568, 96, generator=g).bfloat16().to(gpu)
+    b = torch.randn(1568, 512, generator=g).bfloat16().to(gpu)
+    got = ssi._tn_splitk_impl(a, b)
+    ref = a.double().t() @ b.double()
+    rounded = (a.t() @ b).float()
+    assert got.dtype == torch.float32 and got.shape == (96, 512)
+    e_new, e_old = rel_l2(got.cpu(), ref.cpu()), rel_l2(rounded.cpu(), ref.cpu())
+    assert e_new <= 2e-3 and e_new <= e_old * 1.05, (e_new, e_old)
