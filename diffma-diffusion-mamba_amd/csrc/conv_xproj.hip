@@ -75,9 +75,16 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_fwd_kernel(const dm_
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int nt = wave & 3, kh = wave >> 2;
     const int g = lane >> 4, ij = lane & 15;
-    const int s = blockIdx.x;                                        // dir * batch + b
-    const int dir = s / p.batch;
-    const int b = s - dir * p.batch;
+    // Workgroup id -> (sample, direction) with the direction FASTEST: the ndir gathered sequences of one sample read the same x rows
+    // (in different orders) and now do so at about the same time, so two of the three reads are served on chip instead of from HBM.
+    // (Sequence-major order ran all samples of direction 0 first: by the time direction 1 came round, x had been flushed by the
+    // 655 MB of output written in between.)  DM_K3X_DIRFAST=0 restores the old order.
+#ifndef DM_K3X_DIRFAST
+#define DM_K3X_DIRFAST 1
+#endif
+    const int b = DM_K3X_DIRFAST ? (int)blockIdx.x / p.ndir : (int)blockIdx.x % p.batch;
+    const int dir = DM_K3X_DIRFAST ? (int)blockIdx.x % p.ndir : (int)blockIdx.x / p.batch;
+    const int s = dir * p.batch + b;
     const int L = p.seqlen;
     const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;     // scalar loads
     const bool act = (D == 2 * XP_THREADS) ? true : (2 * tid < D);     // compile-time true for dim 1024
