@@ -78,12 +78,9 @@ __global__ __launch_bounds__(XP_THREADS, 4) void conv_xproj_fwd_kernel(const dm_
     // Workgroup id -> (sample, direction) with the direction FASTEST: the ndir gathered sequences of one sample read the same x rows
     // (in different orders) and now do so at about the same time, so two of the three reads are served on chip instead of from HBM.
     // (Sequence-major order ran all samples of direction 0 first: by the time direction 1 came round, x had been flushed by the
-    // 655 MB of output written in between.)  DM_K3X_DIRFAST=0 restores the old order.
-#ifndef DM_K3X_DIRFAST
-#define DM_K3X_DIRFAST 1
-#endif
-    const int b = DM_K3X_DIRFAST ? (int)blockIdx.x / p.ndir : (int)blockIdx.x % p.batch;
-    const int dir = DM_K3X_DIRFAST ? (int)blockIdx.x % p.ndir : (int)blockIdx.x / p.batch;
+    // 655 MB of output written in between: 257-271 -> 253-258 us.)
+    const int b = (int)blockIdx.x / p.ndir;
+    const int dir = (int)blockIdx.x % p.ndir;
     const int s = dir * p.batch + b;
     const int L = p.seqlen;
     const cptr<int32_t> idx = IDX ? as_const(p.row_index + (int64_t)dir * L) : nullptr;     // scalar loads

@@ -35,9 +35,6 @@
 #include <type_traits>
 #include "dm_common.h"
 
-#ifndef DM_K2_ONE_FENCE
-#define DM_K2_ONE_FENCE 0        // one asm fence over all 16 dA accumulators instead of 16 (s_nop 130 -> 56 per 8 steps, +33 moves): no change in time (2574-2584 us both), off
-#endif
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
 #endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
@@ -163,28 +160,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // (registers go to LDS in groups of 4: [group][lane][4] keeps every ds_write_b128 and the strided flush reads conflict-free)
     static_assert(R % 4 == 0, "lane-group totals are stored 4 registers at a time");
     constexpr int RED_HALF = WAVE * 4 + 4 * 8;
-    // TRRED (round 3): dB[n] = sum_c G[c][n] * du[c] and dC[n] = sum_c h[c][n] * gy[c] are matrix-vector products over the wave's 64
-    // channels, so the matrix pipe can do the PRODUCTS as well as the sums -- once the operands are in fragment layout.  Each lane
-    // writes its 16 states (bf16) as one 32-byte row of a wave-private LDS image [channel][state]; `ds_read_b64_tr_b16` hands lane
-    // (g, n) the column n of 4 channel rows = half a B fragment (k = channel, j = state), two reads per K = 32; the vector (gy or
-    // du, bf16, [channel]) is the A fragment's row 0 (the other 15 rows read a block of zeros).  Two v_mfma_f32_16x16x32_bf16
-    // (K = 64 channels) per quantity leave dB[n] / dC[n], summed over ALL 64 lanes, in register 0 of lanes 0..15: no per-lane
-    // products (16 v_pk_mul_f32 per step), no selector fragments, no 16-row-position sum at the chunk end (64 -> 4 LDS reads per
-    // output in the flush), 75 -> 24 KB of LDS.  h, G, gy, du are rounded to bf16 instead of their products.
-#ifndef DM_K2_TRRED
-#define DM_K2_TRRED 0           // measured (profiles/r03_k2_experiments.txt #6): VALU instructions 193 -> 168 per wave-step, but +2..4 % time -- OFF
-#endif
-    constexpr bool TRRED = DM_K2_TRRED && MFMA_RED && SPLIT == 1 && N == 16 && !HAS_Z;    // (with z the extra registers spill: the legacy call pattern keeps the selector scheme)
-    constexpr int RED_ROW = TRRED ? 2 * N : (R / 4) * RED_HALF;
+    constexpr int RED_ROW = (R / 4) * RED_HALF;
     __shared__ __attribute__((aligned(16))) float red_lds[BWD_WAVES][CK][RED_ROW];
-    // LDS image per wave and buffer (two buffers: step j is staged while step j+1's image is multiplied, so no MFMA waits for a
-    // write it just issued): [h | G][state half][channel][8 states] -- 16-byte rows, consecutive lanes write consecutive slots -- with
-    // 64 B between the halves so that the 8-byte pieces a lane group's transpose read gathers (4 channel rows x 2 halves) fall on 32
-    // different banks; then [gy | du][channel].  (First layout, 32-byte rows [channel][16 states] in one buffer: LDS bank conflicts
-    // 16 -> 51 and LDS wait cycles 14 -> 71 per wave-step, no gain over the selector scheme.)
-    constexpr int TR_HALF = WAVE * 8 + 32, TR_IMG = 2 * TR_HALF, TR_VEC = 2 * TR_IMG, TR_BUF = TR_VEC + 2 * WAVE;     // uint16 units
-    __shared__ __attribute__((aligned(16))) uint16_t tr_lds[TRRED ? BWD_WAVES : 1][2][TRRED ? TR_BUF : 8];
-    __shared__ __attribute__((aligned(16))) uint16_t tr_zero[TRRED ? WAVE : 8];
     __shared__ __attribute__((aligned(16))) float bc_lds[2][CK][2 * N];   // [B row | C row] of every step of a chunk, all waves share a sequence
 
     const int tid = threadIdx.x;
@@ -244,48 +221,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     float dD_acc = 0.f, dbias_acc = 0.f;
 
     u32x4_t sel_lo, sel_hi;
-    if (MFMA_RED && !TRRED) mfma_selectors(lane, sel_lo, sel_hi);
-    typedef short tr_v4s __attribute__((ext_vector_type(4)));
-    typedef __attribute__((address_space(3))) tr_v4s* tr_lds_ptr;
-    // transpose read, lane group g = lane >> 4, L = lane & 15: lane L supplies the 8-byte piece (row 8g + (L >> 2), states
-    // 4 (L & 3) ..) and RECEIVES column L of the 4 x 16 block of rows 8g .. 8g + 3
-    const int tr_g = lane >> 4, tr_L = lane & 15;
-    uint16_t* const tr_base = &tr_lds[TRRED ? wave : 0][0][0];
-    // element offsets inside a buffer: the piece this lane supplies to a transpose read (image 0 = h, + TR_IMG for G), its row slot
-    // for the writes, and the A-fragment source (row 0 of the fragment = the vector, every other row = zeros)
-    const int tr_rd_off = ((tr_L & 3) >> 1) * TR_HALF + (8 * tr_g + (tr_L >> 2)) * 8 + (tr_L & 1) * 4;
-    const int tr_wr_off = lane * 8;
-    const bool tr_row0 = TRRED && tr_L == 0;
-    if (TRRED) {
-        if (tid < WAVE) tr_zero[tid] = 0;
-    }
-    // dC = h^T gy and dB = G^T du of the step staged in buffer `b`: two v_mfma_f32_16x16x32_bf16 each (K = 64 channels);
-    // row 0 of the results (lanes 0..15, register 0) goes to the chunk's partial rows
-    auto tr_multiply = [&](int b, int jstep) {
-        const uint16_t* const buf = tr_base + b * TR_BUF;
-        f32x4 accq[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {                  // m = 0: dC = h^T gy ; m = 1: dB = G^T du
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {           // channels 32 kk .. 32 kk + 31
-                const uint16_t* const src = buf + m * TR_IMG + tr_rd_off + (32 * kk) * 8;
-                const tr_v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_ptr)src);
-                const tr_v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_ptr)(src + 4 * 8));
-                typedef uint32_t tr_u32x2 __attribute__((ext_vector_type(2)));
-                const tr_u32x2 w0 = __builtin_bit_cast(tr_u32x2, b0), w1 = __builtin_bit_cast(tr_u32x2, b1);
-                const u32x4_t bf = {w0.x, w0.y, w1.x, w1.y};
-                const uint16_t* const asrc = tr_row0 ? buf + TR_VEC + m * WAVE + 8 * tr_g + 32 * kk : &tr_zero[0];
-                const u32x4_t af = *reinterpret_cast<const u32x4_t*>(asrc);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, af), __builtin_bit_cast(bf16x8_t, bf), acc, 0, 0, 0);
-            }
-            accq[m] = acc;
-        }
-        if (lane < 16) {                                // D[0][n], n = lane
-            red_lds[wave][jstep][lane] = accq[1][0];        // dB
-            red_lds[wave][jstep][N + lane] = accq[0][0];    // dC
-        }
-    };
+    if (MFMA_RED) mfma_selectors(lane, sel_lo, sel_hi);
     const int red_slot = lane * 4 + (lane >> 4) * 8;                 // + RED_HALF per group of 4 registers
 
     // B/C rows of a chunk: CK*2N values, fetched cooperatively (one or two per thread), one chunk ahead
@@ -316,7 +252,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     // and store its dB/dC partial rows
     auto flush_dbc = [&](int chunk) {
         const int l0 = chunk * CK;
-        if constexpr (MFMA_RED && !TRRED && SPLIT == 1 && N == 16) {
+        if constexpr (MFMA_RED && SPLIT == 1 && N == 16) {
             // 16-byte reads: a thread owns a QUAD of outputs (4 consecutive registers of a lane slot are 4 consecutive values) and a
             // quarter of the 16 row positions; the four quarter-owners are neighbouring lanes and meet through two quad-permute adds.
             // 16 ds_read_b128 per thread and chunk instead of 64 ds_read_b32 (8 -> 2 LDS instructions per step; the dword form also ran
@@ -350,20 +286,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             // rows past the end of the sequence (and threads past the chunk's values) store out of range: dropped, no branch
             const int vo_p = (in && l0 + j < L) ? (((l0 + j) * nwg + (int)blockIdx.x) * (2 * N) + cc) * 4 : BIO_OOB;
             float acc = 0.f;
-            if constexpr (TRRED) {
+            const int n = (cc < N) ? cc : cc - N;
+            const int qq = n / NS;
+            const int vidx = (cc < N) ? n % NS : NS + n % NS;                 // value index in [0, M) inside slice qq
+            const int lane0 = (MFMA_RED ? 16 * ((vidx & 15) >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
+            const int reg = MFMA_RED ? 4 * (vidx >> 4) + (vidx & 3) : (vidx >> 2);
 #pragma unroll
-                for (int w = 0; w < BWD_WAVES; ++w) acc += red_lds[w][j][cc];
-            } else {
-                const int n = (cc < N) ? cc : cc - N;
-                const int qq = n / NS;
-                const int vidx = (cc < N) ? n % NS : NS + n % NS;                 // value index in [0, M) inside slice qq
-                const int lane0 = (MFMA_RED ? 16 * ((vidx & 15) >> 2) : 32 * (vidx & 1) + 16 * ((vidx >> 1) & 1)) + qq;
-                const int reg = MFMA_RED ? 4 * (vidx >> 4) + (vidx & 3) : (vidx >> 2);
+            for (int w = 0; w < BWD_WAVES; ++w)
 #pragma unroll
-                for (int w = 0; w < BWD_WAVES; ++w)
-#pragma unroll
-                    for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(reg >> 2) * RED_HALF + (lane0 + SPLIT * t) * 4 + (lane0 >> 4) * 8 + (reg & 3)];
-            }
+                for (int t = 0; t < 16 / SPLIT; ++t) acc += red_lds[w][j][(reg >> 2) * RED_HALF + (lane0 + SPLIT * t) * 4 + (lane0 >> 4) * 8 + (reg & 3)];
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), r_dbc, vo_p, 0, 0);
         }
     };
@@ -571,16 +502,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
                     dlA2 += A2[k] * Gt;
                     dA[k] += Gt * dlo;
-#if !DM_K2_ONE_FENCE
                     dA[k].x = opaque(dA[k].x);                   // accumulate NOW: left alone the scheduler defers all 8 steps'
                     dA[k].y = opaque(dA[k].y);                   // products to the chunk end and keeps 64 VGPRs alive for them
-#endif
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
-                    if constexpr (TRRED) {
-                        pk_all[k] = pack_bf16(G.x, G.y);             // the matrix pipe multiplies: operands, not products
-                        pk_all[NPL + k] = pack_bf16(hj.x, hj.y);
-                    } else if constexpr (MFMA_RED) {
+                    if constexpr (MFMA_RED) {
                         pk_all[k] = pack_bf16(dBp.x, dBp.y);
                         pk_all[NPL + k] = pack_bf16(dCp.x, dCp.y);
                     } else {
@@ -591,18 +517,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                     h[k] = hp;
                 }
-#if DM_K2_ONE_FENCE
-                // accumulate dA NOW (left alone the scheduler defers all 8 steps' products to the chunk end and keeps 64 VGPRs alive
-                // for them).  ONE empty asm statement over all accumulators: hipcc follows every inline-asm statement with an
-                // `s_nop 0`, and the per-register form of rounds 1-2 cost 16 of them per step (130 of the loop's ~2 100 instructions).
-                if constexpr (NPL == 8) {
-                    asm volatile("" : "+v"(dA[0].x), "+v"(dA[0].y), "+v"(dA[1].x), "+v"(dA[1].y), "+v"(dA[2].x), "+v"(dA[2].y), "+v"(dA[3].x), "+v"(dA[3].y),
-                                      "+v"(dA[4].x), "+v"(dA[4].y), "+v"(dA[5].x), "+v"(dA[5].y), "+v"(dA[6].x), "+v"(dA[6].y), "+v"(dA[7].x), "+v"(dA[7].y));
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NPL; ++k) { dA[k].x = opaque(dA[k].x); dA[k].y = opaque(dA[k].y); }
-                }
-#endif
                 const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[i];
                 const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
                 const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
@@ -626,18 +540,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 } else if constexpr ((DM_K2_EXP & 32) != 0 && MFMA_RED) {       // products + conversions only: no MFMA, no LDS write (flush: bit 2)
 #pragma unroll
                     for (int k = 0; k < M / 2; ++k) asm volatile("" ::"v"(pk_all[k]));
-                } else if constexpr (TRRED) {
-                    // (1) multiply the image staged by the PREVIOUS step (j + 1): its LDS writes retired a whole step ago
-                    if (j < CK - 1) tr_multiply((j + 1) & 1, j + 1);
-                    // (2) stage this step: rows of the two images (operands, not products), the two vector entries
-                    uint16_t* const buf = tr_base + (j & 1) * TR_BUF;
-                    *reinterpret_cast<u32x4_t*>(buf + TR_IMG + tr_wr_off) = (u32x4_t){pk_all[0], pk_all[1], pk_all[2], pk_all[3]};                 // G, states 0..7
-                    *reinterpret_cast<u32x4_t*>(buf + TR_IMG + TR_HALF + tr_wr_off) = (u32x4_t){pk_all[4], pk_all[5], pk_all[6], pk_all[7]};      // G, states 8..15
-                    *reinterpret_cast<u32x4_t*>(buf + tr_wr_off) = (u32x4_t){pk_all[8], pk_all[9], pk_all[10], pk_all[11]};                        // h
-                    *reinterpret_cast<u32x4_t*>(buf + TR_HALF + tr_wr_off) = (u32x4_t){pk_all[12], pk_all[13], pk_all[14], pk_all[15]};
-                    const uint32_t vv = pack_bf16(gy, du);
-                    buf[TR_VEC + lane] = (uint16_t)(vv & 0xffffu);
-                    buf[TR_VEC + WAVE + lane] = (uint16_t)(vv >> 16);
                 } else if constexpr (MFMA_RED) {
 #pragma unroll
                     for (int g16 = 0; g16 < M / 16; ++g16) {   // 16 values (8 pairs) per pair of MFMAs; register r of group g16 = value 16*g16 + 4*(lane>>4) + r
@@ -654,7 +556,6 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 }
             }
         }
-        if constexpr (TRRED && !(DM_K2_EXP & 1)) tr_multiply(0, 0);       // the chunk's last processed step (j = 0) is still staged
         if (!(DM_K2_EXP & 2)) __syncthreads();
         if (!(DM_K2_EXP & 35)) flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);
@@ -676,10 +577,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
-#ifndef DM_K2_SPLIT16
-#define DM_K2_SPLIT16 1        // lanes per channel at d_state 16: 2 = half the states per lane (<= 168 VGPRs, 3 waves per SIMD); measured in round 3, see DESIGN.md
-#endif
-template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : (N == 16 ? DM_K2_SPLIT16 : 1); };   // lanes per channel
+// lanes per channel: a whole channel per lane up to d_state 16 (two lanes per channel = 3 waves per SIMD measured +10 % at d_state 16,
+// profiles/r03_k2_experiments.txt), half of one at d_state 32
+template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : 1; };
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {

@@ -137,8 +137,8 @@ class GraphedTrainStep:
         # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
         # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
         # gradients inside the graph and handed to the fused AdamW, which then leaves weights, moments and step count alone.
-        # `skipped` counts such steps; the host reads it when it logs.  (The EMA line still runs: it blends towards weights that
-        # did not move, a 1 - decay step in place -- it cannot be poisoned.)
+        # `skipped` counts such steps; the host reads it when it logs.  The EMA blend is gated by the same device flag (the reference
+        # `continue`s before update_ema, train.py:254-264): ema <- model + d * (ema - model) with d = decay, or 1 on a dropped step.
         self._one = torch.ones((), device=z.device)
         self.skipped = torch.zeros((), device=z.device)
         with torch.cuda.device(z.device):
@@ -193,8 +193,10 @@ class GraphedTrainStep:
         with torch.no_grad():
             self.skipped += found
             if self.ema is not None:
-                torch._foreach_mul_(self._ep, self.decay)
-                torch._foreach_add_(self._ep, self._mp, alpha=1 - self.decay)
+                d = found * (1.0 - self.decay) + self.decay          # 0-dim device tensor: decay, or 1.0 when the step was dropped
+                torch._foreach_sub_(self._ep, self._mp)
+                torch._foreach_mul_(self._ep, d)
+                torch._foreach_add_(self._ep, self._mp)
 
     # ---- the data-parallel form: graph 1 | all-reduce | graph 2 ----------------------------------------------------------
     def _fwd_bwd(self):

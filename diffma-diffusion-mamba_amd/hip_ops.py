@@ -373,19 +373,6 @@ def gather_conv1d_fwd(x, weight, bias, *, row_index=None, ndir=1, silu=True, out
 XPROJ_FUSED_MIN_SEQS = 512
 
 
-# Directions accumulated by the forward scan (DM_FLAG_OUT_ACCUMULATE, one launch per direction) instead of a separate token_merge
-# pass: measured a wash in round 2 (the three per-direction launches cost 45.2 ms per step against 39.6 ms for the one 3-direction
-# launch, the merge they replaced 4.9 ms), it rounds the running sum to the I/O dtype after every direction, and since
-# round 3 the merge is where the SiLU(z) gate lives.  The model path no longer takes it (the DIFFMA_ACC_DIRS switch is gone); the
-# kernel flag stays in the ABI and keeps its kernel-level test (scan_fwd(..., acc_dirs=True)).
-ACC_DIRS_MIN_WAVES = None
-
-
-def scan_acc_dirs_ok(u, ndir, N, a_shared=False):
-    S, L, Dm = u.shape
-    return (ACC_DIRS_MIN_WAVES is not None and ndir > 1 and N == 16 and not a_shared and S * ((Dm + 63) // 64) >= ACC_DIRS_MIN_WAVES)
-
-
 def conv_xproj_supported(x, wx, nseq, width=4):
     """True when dm_gather_conv1d_xproj_fwd serves this call (16-bit I/O, dim in {128..1024}, <= 64 projection rows, an
     instantiated conv width: once the fused path is chosen there is no fallback, so the predicate must know -- ADVICE r2)."""

@@ -61,22 +61,30 @@ def main(args):
     real = None
     if not args.get("synthetic", False) and args.get("ct_image_folder_val", None):
         # the reference's validation path (sample.py:71-110) through the seam of data.py: conditioning from the CT slice, the
-        # samples decoded by the VAE.  Shard = every world-th item (DistributedSampler without shuffle would pad; the tail is dropped)
+        # samples decoded by the VAE.  Shard = every world-th item (DistributedSampler without shuffle would pad; here the last batch is simply shorter)
         from .data import NpyDataset, build_encoders, prepare_batch, transform_test, VAE_SCALE
         if ct_encoder is None:
             raise FileNotFoundError(f"sampling from data needs the CT_Encoder checkpoint `ct_ckpt` ({args.get('ct_ckpt', None)!r} not found)")
         ds = NpyDataset(args.ct_image_folder_val, args.mask_image_folder_val, args.mir_image_folder_val, transform=transform_test)
         real = dict(ds=ds, enc=build_encoders(args, device), order=list(range(rank, len(ds), world)), decoded=[])
-    for b in range(int(args.get("num_batches", 1))):
-        z = mk(n, 4, latent, latent)
+    # Sampling from data walks the WHOLE validation shard, ragged tail included, like the reference's loader (drop_last=False,
+    # sample.py:84-110); `num_batches` caps it when given.  Synthetic runs default to one batch.
+    nb_default = -(-len(real["order"]) // n) if real is not None else 1
+    nb = args.get("num_batches", None)
+    for b in range(int(nb) if nb is not None else nb_default):
+        nb_cur = n
         if real is not None:
             ids = real["order"][b * n:(b + 1) * n]
-            if len(ids) < n:
+            if not ids:
                 break
+            nb_cur = len(ids)
             items = [real["ds"][j] for j in ids]
             _, y_, y2_, w_, _, _ = prepare_batch(torch.stack([it[0] for it in items]), torch.stack([it[2] for it in items]), real["enc"],
-                                                 ct_encoder, device)
+                                                 ct_encoder, device, encode_target=False)
             kw = dict(y=y_, y2=y2_, w=w_)
+        z = mk(nb_cur, 4, latent, latent)
+        if real is not None:
+            pass                                       # conditioning prepared above
         elif ct_encoder is not None:                   # soft mask + token conditioning from the CT latent (reference sample.py:104)
             with torch.no_grad():
                 ct_w, ct_y2 = ct_encoder(mk(n, 4, latent, latent))
@@ -85,7 +93,7 @@ def main(args):
             kw = dict(y=mk(n, 512), y2=mk(n, tokens, 512), w=torch.sigmoid(mk(n, tokens, 1)))
         loop = diffusion.ddim_sample_loop if ddim else diffusion.p_sample_loop
         denoiser = model.forward
-        if device.type == "cuda" and not args.get("no_graph", False):
+        if device.type == "cuda" and not args.get("no_graph", False) and nb_cur == n:      # the ragged tail batch runs eagerly
             if graphed is None:
                 from .graphed import GraphedDenoiser  # shapes are static over all steps: capture once, replay per step
                 graphed = GraphedDenoiser(model, z, torch.zeros(n, device=device, dtype=torch.long), kw["y"], kw["y2"], kw["w"])

@@ -282,7 +282,8 @@ class _SpiralSSMFn(torch.autograd.Function):
         hoist = HOIST_GATE and merge and out_index is None and ndir > 1
         # Hoisted softplus: delta = softplus(dt_proj(.) + bias) leaves the dt_proj kernel activated (csrc/dtproj.hip) and the scans
         # run with DM_FLAG_DELTA_ACTIVATED (forward: nothing to evaluate; backward: only 1 - exp(-delta)).
-        act = hoist and hip_ops.dtproj_softplus_supported(x_dbl, Wdt_c)
+        # The backward of that flag exists for d_state 16 only (csrc/scan_bwd.hip): other widths keep the softplus inside the scans.
+        act = hoist and N == 16 and hip_ops.dtproj_softplus_supported(x_dbl, Wdt_c)
         if act:
             delta = hip_ops.dtproj_softplus_fwd(x_dbl, Wdt_c, dt_bias).view(ndir * Bsz, L, Din)
         else:
@@ -301,12 +302,9 @@ class _SpiralSSMFn(torch.autograd.Function):
             y = hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din), gate=z_view, pre_out=pre)
             ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx, pre)
             return y
-        acc = merge and hip_ops.scan_acc_dirs_ok(xc, ndir, N)      # the 3-way CrossMerge sum done by the scan itself
         ydir = hip_ops.scan_fwd(xc, delta, A, Bm, Cm, Dskip, z_view, dt_bias, True, z_row_index=scan_index,
-                                out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt, acc_dirs=acc)     # token order
+                                out_row_index=oidx, batch_per_dir=Bsz, ckpt=ckpt)                   # token order
         ctx.save_for_backward(xz, conv_w, conv_b, Wx, Wdt, dt_bias, A, Dskip, scan_index, xc, x_dbl, delta, ckpt, Wx_c, Wdt_c, oidx, None)
-        if acc:
-            return ydir                                            # [B, L, Din], already merged
         if not merge:
             return ydir.view(ndir, Bsz, L, Din)
         return hip_ops.token_merge(ydir.view(ndir, Bsz, L, Din)) if ndir > 1 else ydir

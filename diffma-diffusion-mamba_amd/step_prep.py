@@ -20,6 +20,18 @@ ENABLED = os.environ.get("DIFFMA_STEP_PREP", "1") == "1"
 _PLANS = weakref.WeakKeyDictionary()
 _SHADOWS = {}            # id(master) -> (weakref to the master, shadow tensor, master version when copied); the weakref guards against
                          # id() reuse after a model is freed (a NEW parameter with the id and version of a dead one must not get its shadow)
+                         # and its callback drops the entry (and with it the shadow's device memory) when the master dies
+
+
+def _register(w, shadow):
+    key = id(w)
+
+    def _gone(ref, key=key):
+        ent = _SHADOWS.get(key)
+        if ent is not None and ent[0] is ref:
+            del _SHADOWS[key]
+
+    _SHADOWS[key] = (weakref.ref(w, _gone), shadow, w._version)
 
 
 class _NegExpAll(torch.autograd.Function):
@@ -66,8 +78,9 @@ def cast_weight(weight, dtype):
     return s if s is not None else weight.to(dtype)
 
 
-def prepare(model):
-    """Called at the top of DiffMa.forward when gradients are on and the model is on a ROCm device."""
+def prepare(model, dtype=None):
+    """Called at the top of DiffMa.forward when gradients are on and the model is on a ROCm device.  dtype: the 16-bit dtype of the
+    weight copies (default: the active CUDA autocast dtype; tests pass it explicitly)."""
     if not ENABLED:
         return
     plan = _PLANS.get(model)                        # per model, outside its __dict__: deepcopy / state_dict never see it
@@ -90,12 +103,24 @@ def prepare(model):
         As = _NegExpAll.apply(*[m.A_log for m in mixers])
         for m, a in zip(mixers, As):
             m.__dict__["_A_step"] = a
-    dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+    dt = dtype if dtype is not None else (torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None)
     if dt in (torch.bfloat16, torch.float16) and plan["masters"]:
+        masters = plan["masters"]
         sh = plan["shadows"].get(dt)
-        if sh is None or sh[0].device != plan["masters"][0].device:
-            sh = plan["shadows"][dt] = [torch.empty_like(w, dtype=dt) for w in plan["masters"]]
+        fresh = sh is None or sh[0].device != masters[0].device
+        capturing = masters[0].is_cuda and torch.cuda.is_current_stream_capturing()
+        if not fresh and not capturing:
+            if all(shadow_of(w, dt) is s for w, s in zip(masters, sh)):
+                # Every shadow is current (no master written since the last prepare): nothing to copy.  This is also what keeps a
+                # SECOND forward before the first one's backward legal: the shadows are saved for backward by the projections'
+                # autograd nodes, and an in-place refresh would invalidate the first graph.
+                return
+            # Masters were written (an optimizer step).  If an autograd graph still holds the old copies (retain_graph, a backward
+            # that has not run yet) they must not be overwritten: new buffers, the old ones die with that graph.
+            fresh = any(s._use_count() > 1 for s in sh)
+        if fresh:
+            sh = plan["shadows"][dt] = [torch.empty_like(w, dtype=dt) for w in masters]
         with torch.no_grad():
-            torch._foreach_copy_(sh, [w.detach() for w in plan["masters"]])
-        for w, s in zip(plan["masters"], sh):
-            _SHADOWS[id(w)] = (weakref.ref(w), s, w._version)
+            torch._foreach_copy_(sh, [w.detach() for w in masters])
+        for w, s in zip(masters, sh):
+            _register(w, s)

@@ -201,6 +201,7 @@ def main(args):
     ddp.train()
     ema.eval()
     log_steps, running_loss, start_time = 0, 0.0, time()
+    skipped_seen = 0                     # graphed steps dropped on the device that the step counter has already been corrected for
     max_steps = args.get("max_steps", None)
     amp = (torch.float16 if args.get("amp_dtype", "bf16") == "fp16" else torch.bfloat16) if args.autocast else None
     scaler = torch.amp.GradScaler(device.type, enabled=amp == torch.float16)     # no-op unless fp16 (reference train.py:95)
@@ -223,8 +224,10 @@ def main(args):
                     # non-finite steps were dropped ON THE DEVICE (found_inf from the all-reduced gradients, the same decision on
                     # every rank: graphed.GraphedTrainStep._guarded_update); the host only reports them
                     lv, nskip = loss.item(), int(graphed.skipped.item())
-                    if nskip:
+                    if nskip > skipped_seen:                    # dropped steps do not count as optimisation steps (reference `continue`)
                         logger.info(f"nan......      ignore losses......   ({nskip} graphed steps skipped so far)")
+                        train_steps -= nskip - skipped_seen
+                        skipped_seen = nskip
                     running_loss = (lv if math.isfinite(lv) else 0.0) * log_steps   # the log line shows the latest loss instead of a running mean
             else:
                 with torch.autocast(device.type, dtype=amp, enabled=amp is not None):

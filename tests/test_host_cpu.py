@@ -294,13 +294,63 @@ def _real_data_worker(rank, world, port, tmpdir):
     assert steps == 2
     ck = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(tmpdir) for f in fs if f.endswith("0000002.pt"))
     out = sample_mod.main(Config(ckpt=ck[0], load_ckpt_type="ema", save_dir=os.path.join(tmpdir, "samples"), seed=0,
-                                 sample_global_batch_size=2, sample_num_steps=2, num_batches=1, **base))
-    assert out[0].shape == (2, 4, 28, 28)
+                                 sample_global_batch_size=3, sample_num_steps=2, **base))
+    # no num_batches: the whole validation shard (4 slices) is sampled, the ragged last batch included (reference drop_last=False)
+    assert [tuple(o.shape) for o in out] == [(3, 4, 28, 28), (1, 4, 28, 28)]
     img = torch.load(os.path.join(tmpdir, "samples", "images_rank0.pt"))
-    assert img.shape == (2, 3, 224, 224) and torch.isfinite(img).all()
+    assert img.shape == (4, 3, 224, 224) and torch.isfinite(img).all()
 
 
 def test_train_and_sample_on_the_real_data_path_with_fake_encoders(tmp_path):
     """train.main / sample.main with `synthetic: false`: .npy slices -> NpyDataset -> (stand-in) VAE / CLIP + CT_Encoder -> denoiser,
     and the sampler's VAE decode at the end (reference train.py:186-243, sample.py:71-110)."""
     mp.spawn(_real_data_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+
+
+def test_step_prep_shadows_survive_two_forwards_and_a_retained_graph():
+    """the 16-bit weight copies of step_prep are saved for backward by the projections' autograd nodes.  A second
+    prepare() must not write them in place while a graph still holds them: unchanged masters -> no copy at all; changed masters
+    with a live graph -> new buffers; changed masters with no live graph -> in place (the steady state of a training loop)."""
+    from diffma_amd import step_prep
+    from diffma_amd.mamba import Mamba
+    from diffma_amd.selective_scan_interface import linear_splitk
+
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(Mamba(32, d_state=16))      # prepare() takes the MODEL (its plan holds the mixers, not the model itself)
+    x = torch.randn(2, 5, 32)
+    W = m[0].in_proj.weight
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        step_prep.prepare(m, dtype=torch.bfloat16)
+        s0 = step_prep.shadow_of(W, torch.bfloat16)
+        assert s0 is not None and s0.dtype == torch.bfloat16
+        y1 = linear_splitk(x, W)
+        step_prep.prepare(m, dtype=torch.bfloat16)                      # second forward of the same step: nothing is rewritten
+        assert step_prep.shadow_of(W, torch.bfloat16) is s0
+        y2 = linear_splitk(x, W)
+        (y1.float().sum() + y2.float().sum()).backward()                # used to raise "modified by an inplace operation"
+        g_two = W.grad.clone()
+        W.grad = None
+        # a retained graph across a weight update: the old copy must stay what the graph saw
+        y3 = linear_splitk(x, W)
+        with torch.no_grad():
+            W.add_(1.0)
+        step_prep.prepare(m, dtype=torch.bfloat16)
+        s1 = step_prep.shadow_of(W, torch.bfloat16)
+        assert s1 is not None and s1 is not s0                          # new buffers, because y3's graph holds s0
+        torch.testing.assert_close(s1.float(), W.detach().to(torch.bfloat16).float())
+        y3.float().sum().backward()
+        torch.testing.assert_close(W.grad, g_two / 2, rtol=1e-2, atol=1e-2)
+        # steady state: no live graph, masters written -> refreshed in place
+        del y1, y2, y3
+        with torch.no_grad():
+            W.mul_(0.5)
+        step_prep.prepare(m, dtype=torch.bfloat16)
+        assert step_prep.shadow_of(W, torch.bfloat16) is s1
+        torch.testing.assert_close(s1.float(), W.detach().to(torch.bfloat16).float())
+    # a dead master takes its entry (and the shadow's memory) with it
+    key = id(W)
+    assert key in step_prep._SHADOWS
+    del m, W
+    import gc
+    gc.collect()
+    assert key not in step_prep._SHADOWS
