@@ -139,6 +139,8 @@ def load():
                 fn.argtypes = [ctypes.c_int] * 5
             elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported", "dm_dtproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            elif name.endswith("_n"):                    # an array of n argument structs (several congruent launches in one)
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
             else:
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         got = lib.dm_abi_version()
@@ -159,6 +161,24 @@ def call(name: str, args_struct, stream_handle: int):
     lib = load()
     status = getattr(lib, name)(ctypes.byref(args_struct), ctypes.c_void_p(stream_handle))
     check(status, name)
+
+
+def call_n(name: str, args_structs, stream_handle: int):
+    """`name`_n(args[0..n), n, stream): the structs must be of one ctypes type; congruent neighbours share a launch."""
+    lib = load()
+    arr = (type(args_structs[0]) * len(args_structs))(*args_structs)
+    status = getattr(lib, name + "_n")(ctypes.cast(arr, ctypes.c_void_p), len(args_structs), ctypes.c_void_p(stream_handle))
+    check(status, name + "_n")
+
+
+HAS_N = None
+
+
+def has_n(name: str) -> bool:
+    global HAS_N
+    if HAS_N is None:
+        HAS_N = {n[:-2] for n in EXPORTED_SYMBOLS if n.endswith("_n")}
+    return name in HAS_N
 
 
 def build_info() -> str:

@@ -11,6 +11,12 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local const void* g_mix_second = nullptr;
+static thread_local bool g_mix_taken = false;
+const void* mix_peek() { return g_mix_second; }
+void mix_announce(const void* second) { g_mix_second = second; g_mix_taken = false; }
+bool mix_was_taken() { return g_mix_taken; }
+void mix_take() { g_mix_second = nullptr; g_mix_taken = true; }
 }  // namespace dm
 
 extern "C" int dm_abi_version(void) { return DM_ABI_VERSION; }

@@ -52,11 +52,14 @@ template <> struct vio<f16_t, 2> {
 };
 
 template <typename T, typename TW, int W, bool SILU, int VEC>
-__global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) {
+__global__ __launch_bounds__(64) void conv_fwd_kernel(const mix_args<dm_conv_fwd_args> pm) {
+    const int zper = pm.a[0].ndir * pm.a[0].batch;           // grid.z = n launches x (ndir * batch) sequences
+    const int mix = (pm.n > 1 && (int)blockIdx.z >= zper) ? 1 : 0;
+    const dm_conv_fwd_args& p = pm.a[mix];
     const int lane = threadIdx.x;
     const int d0 = blockIdx.x * WAVE * VEC;
     const int c = blockIdx.y;
-    const int s = blockIdx.z;               // dir*batch + b
+    const int s = blockIdx.z - mix * zper;  // dir*batch + b
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
@@ -113,13 +116,16 @@ __global__ __launch_bounds__(64) void conv_fwd_kernel(const dm_conv_fwd_args p) 
 // dw[j] += g[m]*x[idx[m-(W-1)+j]];  db += g[m].   A chunk needs pre/g on [lbeg, lbeg+CH+W-1) and x
 // on [lbeg-(W-1), lbeg+CH+W-1).
 template <typename T, typename TW, int W, bool SILU, int VEC>
-__global__ __launch_bounds__(64 * CONV_BWD_WAVES) void conv_bwd_kernel(const dm_conv_bwd_args p) {
+__global__ __launch_bounds__(64 * CONV_BWD_WAVES) void conv_bwd_kernel(const mix_args<dm_conv_bwd_args> pm) {
+    const int zper = pm.a[0].ndir * pm.a[0].batch;
+    const int mix = (pm.n > 1 && (int)blockIdx.z >= zper) ? 1 : 0;
+    const dm_conv_bwd_args& p = pm.a[mix];
     __shared__ float part_lds[CONV_BWD_WAVES][(W + 1) * VEC][WAVE];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform on purpose: keeps the chunk's row arithmetic scalar
     const int d0 = blockIdx.x * WAVE * VEC;
     const int c = blockIdx.y * CONV_BWD_WAVES + wave;          // chunks past the end of the sequence only contribute zeros
-    const int s = blockIdx.z;
+    const int s = blockIdx.z - mix * zper;
     const int dir = s / p.batch;
     const int b = s - dir * p.batch;
     const int L = p.seqlen;
@@ -247,11 +253,13 @@ static inline bool even4(const void* ptr, std::initializer_list<int64_t> strides
 template <typename T, typename TW, int W, int VEC>
 static void launch_conv_fwd_v(const dm_conv_fwd_args& a, hipStream_t st) {
     const int nchunk = (a.seqlen + CONV_CH - 1) / CONV_CH;
-    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), nchunk, a.ndir * a.batch), block(WAVE);
+    unsigned gz;
+    const mix_args<dm_conv_fwd_args> m = mix_make(a, gz);
+    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), nchunk, a.ndir * a.batch * gz), block(WAVE);
     if (a.flags & DM_FLAG_SILU)
-        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, m);
     else
-        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, m);
 }
 
 template <typename T, typename TW, int W>
@@ -269,11 +277,13 @@ static int launch_conv_fwd(const dm_conv_fwd_args& a, hipStream_t st) {
 
 template <typename T, typename TW, int W, int VEC>
 static void launch_conv_bwd_v(const dm_conv_bwd_args& a, hipStream_t st) {
-    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), a.nchunk, a.ndir * a.batch), block(WAVE * CONV_BWD_WAVES);
+    unsigned gz;
+    const mix_args<dm_conv_bwd_args> m = mix_make(a, gz);
+    dim3 grid((a.dim + WAVE * VEC - 1) / (WAVE * VEC), a.nchunk, a.ndir * a.batch * gz), block(WAVE * CONV_BWD_WAVES);
     if (a.flags & DM_FLAG_SILU)
-        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, true, VEC>), grid, block, 0, st, m);
     else
-        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((conv_bwd_kernel<T, TW, W, false, VEC>), grid, block, 0, st, m);
 }
 
 template <typename T, typename TW, int W>
@@ -327,7 +337,7 @@ extern "C" int dm_gather_conv1d_fwd(const dm_conv_fwd_args* args, void* stream) 
     const dm_conv_fwd_args& a = *args;
     if (!a.x || !a.weight || !a.out) { set_error("dm_gather_conv1d_fwd: null tensor pointer"); return DM_ERR_ARG; }
     if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_fwd: non-positive size"); return DM_ERR_ARG; }
-    if ((int64_t)a.ndir * a.batch > 65535) { set_error("dm_gather_conv1d_fwd: ndir*batch > 65535"); return DM_ERR_ARG; }
+    if ((int64_t)a.ndir * a.batch * DM_MAX_MIX > 65535) { set_error("dm_gather_conv1d_fwd: ndir*batch > 32767"); return DM_ERR_ARG; }
     if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_fwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
     if (a.x_sd != 1 || a.o_sd != 1) { set_error("dm_gather_conv1d_fwd: needs token-major tensors (channel stride 1)"); return DM_ERR_LAYOUT; }
     hipStream_t st = (hipStream_t)stream;
@@ -347,7 +357,7 @@ extern "C" int dm_gather_conv1d_bwd(const dm_conv_bwd_args* args, void* stream) 
     const dm_conv_bwd_args& a = *args;
     if (!a.x || !a.weight || !a.dout || !a.dx || !a.dw_partial) { set_error("dm_gather_conv1d_bwd: null tensor pointer"); return DM_ERR_ARG; }
     if (a.batch <= 0 || a.dim <= 0 || a.seqlen <= 0 || a.ndir <= 0) { set_error("dm_gather_conv1d_bwd: non-positive size"); return DM_ERR_ARG; }
-    if ((int64_t)a.ndir * a.batch > 65535) { set_error("dm_gather_conv1d_bwd: ndir*batch > 65535"); return DM_ERR_ARG; }
+    if ((int64_t)a.ndir * a.batch * DM_MAX_MIX > 65535) { set_error("dm_gather_conv1d_bwd: ndir*batch > 32767"); return DM_ERR_ARG; }
     if (a.ndir > 1 && !a.row_index) { set_error("dm_gather_conv1d_bwd: ndir>1 needs row_index"); return DM_ERR_ARG; }
     if (a.nchunk != dm_conv_nchunk(a.seqlen)) { set_error("dm_gather_conv1d_bwd: nchunk must be dm_conv_nchunk(seqlen)"); return DM_ERR_ARG; }
     if (a.x_sd != 1 || a.do_sd != 1 || a.dx_sd != 1) { set_error("dm_gather_conv1d_bwd: needs token-major tensors"); return DM_ERR_LAYOUT; }
@@ -360,4 +370,30 @@ extern "C" int dm_gather_conv1d_bwd(const dm_conv_bwd_args* args, void* stream) 
         case DM_F16: return wf32 ? conv_bwd_t<f16_t, float>(a, st) : conv_bwd_t<f16_t, f16_t>(a, st);
         default: set_error("dm_gather_conv1d_bwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
     }
+}
+
+// ---- n congruent launches in one (the two mixers of a block at small batch) ------------------------------------------------
+static inline bool same_align4(const void* x, const void* y) { return (((uintptr_t)x ^ (uintptr_t)y) & 3) == 0; }
+
+extern "C" int dm_gather_conv1d_fwd_n(const dm_conv_fwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_gather_conv1d_fwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_conv_fwd_args* a) { return dm_gather_conv1d_fwd(a, stream); },
+                        [](const dm_conv_fwd_args& x, const dm_conv_fwd_args& y) {
+                            return same_align4(x.x, y.x) && same_align4(x.out, y.out) &&      // the 2-channel form is chosen per pointer
+                                   mix_congruent(x, y, &dm_conv_fwd_args::x, &dm_conv_fwd_args::weight, &dm_conv_fwd_args::bias,
+                                                 &dm_conv_fwd_args::row_index, &dm_conv_fwd_args::out);
+                        });
+}
+
+extern "C" int dm_gather_conv1d_bwd_n(const dm_conv_bwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_gather_conv1d_bwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_conv_bwd_args* a) { return dm_gather_conv1d_bwd(a, stream); },
+                        [](const dm_conv_bwd_args& x, const dm_conv_bwd_args& y) {
+                            return same_align4(x.x, y.x) && same_align4(x.dout, y.dout) && same_align4(x.dx, y.dx) &&
+                                   mix_congruent(x, y, &dm_conv_bwd_args::x, &dm_conv_bwd_args::weight, &dm_conv_bwd_args::bias,
+                                                 &dm_conv_bwd_args::row_index, &dm_conv_bwd_args::dout, &dm_conv_bwd_args::dx,
+                                                 &dm_conv_bwd_args::dw_partial, &dm_conv_bwd_args::db_partial);
+                        });
 }

@@ -12,6 +12,62 @@ constexpr int WAVE = 64;
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
+// ---- several congruent launches in one (dm_*_n entry points, include/diffma_hip.h) --------------------------------------
+// The two mixers of a DiffMa block (reference block/mamba_block.py:107-108) run the same kernels on tensors of the same shape
+// with different weights.  At the reference's own batch (config/brain.yaml: one sample per GPU) a training step is bound by
+// the NUMBER of launches, so the small-launch kernels take an ARRAY of argument structs as their kernel argument and pick
+// theirs with blockIdx.z (or a slice of it): one launch, grid.z = n, nothing else changes in the kernel bodies.
+constexpr int DM_MAX_MIX = 2;
+template <typename A> struct mix_args {
+    A a[DM_MAX_MIX];
+    int n;
+};
+// Host side: a dm_*_n entry point announces the second argument struct before it runs the ordinary single-launch path on the
+// first; the launch site of a mix-capable kernel takes it (mix_make) -- any other launch site leaves it, and the entry point
+// then launches the second struct on its own.  Thread-local: the backward runs on autograd's worker thread.
+const void* mix_peek();
+void mix_announce(const void* second);
+bool mix_was_taken();
+void mix_take();
+template <typename A> static inline mix_args<A> mix_make(const A& a, unsigned& gz) {
+    mix_args<A> m;
+    m.a[0] = a;
+    const A* second = static_cast<const A*>(mix_peek());
+    if (second) {
+        m.a[1] = *second;
+        m.n = 2;
+        mix_take();
+    } else {
+        m.a[1] = a;
+        m.n = 1;
+    }
+    gz = (unsigned)m.n;
+    return m;
+}
+// launch loop of a dm_*_n entry point: congruent neighbours share a launch when the kernel their shape selects can take two
+template <typename A, typename F, typename C>
+static inline int mix_launch_n(const A* args, int n, F single, C congruent) {
+    int i = 0;
+    while (i < n) {
+        const bool pair = i + 1 < n && congruent(args[i], args[i + 1]);
+        mix_announce(pair ? &args[i + 1] : nullptr);
+        const int rc = single(&args[i]);
+        const bool taken = mix_was_taken();
+        mix_announce(nullptr);
+        if (rc != 0) return rc;
+        i += (pair && taken) ? 2 : 1;
+    }
+    return 0;
+}
+// all fields equal except the listed pointer members, whose null-ness must agree
+template <typename A, typename... M>
+static inline bool mix_congruent(const A& x, const A& y, M A::*... ptrs) {
+    if ((... || ((x.*ptrs == nullptr) != (y.*ptrs == nullptr)))) return false;
+    A u = x, v = y;
+    ((u.*ptrs = nullptr, v.*ptrs = nullptr), ...);
+    return __builtin_memcmp(&u, &v, sizeof(A)) == 0;
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

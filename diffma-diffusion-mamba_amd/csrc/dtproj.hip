@@ -58,7 +58,8 @@ __device__ __forceinline__ float softplus16_f(float x) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64 * DTP_WAVES) void dtproj_softplus_kernel(const dm_dtproj_args p) {
+__global__ __launch_bounds__(64 * DTP_WAVES) void dtproj_softplus_kernel(const mix_args<dm_dtproj_args> pm) {
+    const dm_dtproj_args& p = pm.a[blockIdx.z];
     constexpr int LROW = DTP_NQ * 64 + 8;                                      // LDS row stride in elements (16 B of padding)
     __shared__ __attribute__((aligned(16))) T stage[DTP_WAVES][16][LROW];
     const int lane = threadIdx.x & 63;
@@ -158,11 +159,13 @@ extern "C" int dm_dtproj_softplus_fwd(const dm_dtproj_args* args, void* stream) 
         set_error("dm_dtproj_softplus_fwd: x_dbl row stride must be a multiple of 8 elements and all tensors 16-byte aligned"); return DM_ERR_LAYOUT;
     }
     const int tiles = (a.rows + 15) / 16;
-    dim3 grid((tiles + DTP_TILES - 1) / DTP_TILES, (a.dim + DTP_WAVES * DTP_NQ * 64 - 1) / (DTP_WAVES * DTP_NQ * 64));
+    unsigned gz;
+    const mix_args<dm_dtproj_args> m = mix_make(a, gz);
+    dim3 grid((tiles + DTP_TILES - 1) / DTP_TILES, (a.dim + DTP_WAVES * DTP_NQ * 64 - 1) / (DTP_WAVES * DTP_NQ * 64), gz);
     if (grid.y > 65535) { set_error("dm_dtproj_softplus_fwd: dim too large"); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
-    if (a.io_dtype == DM_BF16) hipLaunchKernelGGL((dtproj_softplus_kernel<bf16_t>), grid, dim3(64 * DTP_WAVES), 0, st, a);
-    else hipLaunchKernelGGL((dtproj_softplus_kernel<f16_t>), grid, dim3(64 * DTP_WAVES), 0, st, a);
+    if (a.io_dtype == DM_BF16) hipLaunchKernelGGL((dtproj_softplus_kernel<bf16_t>), grid, dim3(64 * DTP_WAVES), 0, st, m);
+    else hipLaunchKernelGGL((dtproj_softplus_kernel<f16_t>), grid, dim3(64 * DTP_WAVES), 0, st, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_dtproj_softplus_fwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
@@ -191,7 +194,8 @@ namespace dm {
 constexpr int DTB_WAVES = 8, DTB_TM = 32;
 
 template <typename T, int KC, int NR>      // KC = 32-channel chunks per wave (CH = 32 KC), NR = 16-wide r tiles (rank = 16 NR)
-__global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtproj_bwd_args p) {
+__global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const mix_args<dm_dtproj_bwd_args> pm) {
+    const dm_dtproj_bwd_args& p = pm.a[blockIdx.z];
     constexpr int CH = 32 * KC, DIM = DTB_WAVES * CH, R = 16 * NR;
     constexpr int LROW = DIM + 16;                 // elements; 32 bytes of padding: the 4 rows x 32 bytes of a transpose read fall on distinct banks
     constexpr int XROW = R + 16;
@@ -340,9 +344,11 @@ __global__ __launch_bounds__(64 * DTB_WAVES) void dtproj_bwd_kernel(const dm_dtp
 
 template <typename T>
 static int dtproj_bwd_launch(const dm_dtproj_bwd_args& a, hipStream_t st) {
-    const dim3 grid((unsigned)a.nblk), block(64 * DTB_WAVES);
+    unsigned gz;
+    const mix_args<dm_dtproj_bwd_args> m = mix_make(a, gz);
+    const dim3 grid((unsigned)a.nblk, 1, gz), block(64 * DTB_WAVES);
     const int kc = a.dim / (32 * DTB_WAVES), nr = a.rank / 16;
-#define DM_DTB(KC, NR) hipLaunchKernelGGL((dtproj_bwd_kernel<T, KC, NR>), grid, block, 0, st, a)
+#define DM_DTB(KC, NR) hipLaunchKernelGGL((dtproj_bwd_kernel<T, KC, NR>), grid, block, 0, st, m)
     switch (kc * 10 + nr) {
         case 21: DM_DTB(2, 1); break;
         case 22: DM_DTB(2, 2); break;
@@ -381,4 +387,24 @@ extern "C" int dm_dtproj_bwd(const dm_dtproj_bwd_args* args, void* stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_dtproj_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
+}
+
+// ---- n congruent launches in one (the two mixers of a block at small batch; see dm_common.h mix_args) ------------------------
+extern "C" int dm_dtproj_softplus_fwd_n(const dm_dtproj_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_dtproj_softplus_fwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_dtproj_args* a) { return dm_dtproj_softplus_fwd(a, stream); },
+                        [](const dm_dtproj_args& x, const dm_dtproj_args& y) {
+                            return mix_congruent(x, y, &dm_dtproj_args::xdbl, &dm_dtproj_args::w, &dm_dtproj_args::bias, &dm_dtproj_args::delta);
+                        });
+}
+
+extern "C" int dm_dtproj_bwd_n(const dm_dtproj_bwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_dtproj_bwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_dtproj_bwd_args* a) { return dm_dtproj_bwd(a, stream); },
+                        [](const dm_dtproj_bwd_args& x, const dm_dtproj_bwd_args& y) {
+                            return mix_congruent(x, y, &dm_dtproj_bwd_args::ddelta, &dm_dtproj_bwd_args::xdbl, &dm_dtproj_bwd_args::w,
+                                                 &dm_dtproj_bwd_args::dxdbl, &dm_dtproj_bwd_args::part);
+                        });
 }

@@ -34,11 +34,13 @@ __device__ __forceinline__ void vec_st(T* dst, const T (&tmp)[VEC]) {
 
 // GATE: out = (sum) * silu(gate row), optional `pre` = the ungated sum (see include/diffma_hip.h)
 template <typename TI, typename TO, int VEC, bool GATE = false>
-__global__ __launch_bounds__(256) void merge_kernel(const dm_merge_args p) {
-    // grid.x covers dim/VEC vectors of one row in blocks of 256 threads; grid.y = seqlen; grid.z = batch
+__global__ __launch_bounds__(256) void merge_kernel(const mix_args<dm_merge_args> pm) {
+    // grid.x covers dim/VEC vectors of one row in blocks of 256 threads; grid.y = seqlen; grid.z = (launches x) batch
+    const int mix = (pm.n > 1 && (int)blockIdx.z >= pm.a[0].batch) ? 1 : 0;
+    const dm_merge_args& p = pm.a[mix];
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z - mix * pm.a[0].batch;
     if (v * VEC >= p.dim) return;
     float acc[VEC];
 #pragma unroll
@@ -94,14 +96,16 @@ static int launch_merge(const dm_merge_args& a, hipStream_t st) {
                   (((uintptr_t)a.in) % 16 == 0) && (((uintptr_t)a.out) % 16 == 0);
     if (a.gate) vec_ok = vec_ok && (a.g_sb % VECMAX == 0) && (a.g_sl % VECMAX == 0) && (((uintptr_t)a.gate) % 16 == 0);
     if (a.pre) vec_ok = vec_ok && (a.p_sb % VECMAX == 0) && (a.p_sl % VECMAX == 0) && (((uintptr_t)a.pre) % 16 == 0);
+    unsigned gz;
+    const mix_args<dm_merge_args> m = mix_make(a, gz);
     if (vec_ok) {
-        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch);
-        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch * gz);
+        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX, true>), grid, dim3(256), 0, st, m);
+        else hipLaunchKernelGGL((merge_kernel<TI, TO, VECMAX>), grid, dim3(256), 0, st, m);
     } else {
-        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch);
-        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, 1, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((merge_kernel<TI, TO, 1>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch * gz);
+        if (a.gate) hipLaunchKernelGGL((merge_kernel<TI, TO, 1, true>), grid, dim3(256), 0, st, m);
+        else hipLaunchKernelGGL((merge_kernel<TI, TO, 1>), grid, dim3(256), 0, st, m);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_token_merge: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
@@ -116,7 +120,7 @@ extern "C" int dm_token_merge(const dm_merge_args* args, void* stream) {
     const dm_merge_args& a = *args;
     if (!a.in || !a.out) { set_error("dm_token_merge: null tensor pointer"); return DM_ERR_ARG; }
     if (a.nin <= 0 || a.batch <= 0 || a.seqlen <= 0 || a.dim <= 0) { set_error("dm_token_merge: non-positive size"); return DM_ERR_ARG; }
-    if (a.batch > 65535 || a.seqlen > 65535) { set_error("dm_token_merge: batch/seqlen > 65535"); return DM_ERR_ARG; }
+    if (a.batch * DM_MAX_MIX > 65535 || a.seqlen > 65535) { set_error("dm_token_merge: batch > 32767 or seqlen > 65535"); return DM_ERR_ARG; }
     if (a.pre && !a.gate) { set_error("dm_token_merge: pre is only written by the gated form (gate != NULL)"); return DM_ERR_ARG; }
     if (a.gate && a.io_dtype != a.out_dtype) { set_error("dm_token_merge: the gated form keeps one dtype (in, gate, pre, out)"); return DM_ERR_DTYPE; }
     hipStream_t st = (hipStream_t)stream;
@@ -136,10 +140,12 @@ extern "C" int dm_token_merge(const dm_merge_args* args, void* stream) {
 // ------------------------------------------------------------------------------------------------------------
 namespace dm {
 template <typename T, int VEC>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const dm_gate_bwd_args p) {
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const mix_args<dm_gate_bwd_args> pm) {
+    const int mix = (pm.n > 1 && (int)blockIdx.z >= pm.a[0].batch) ? 1 : 0;
+    const dm_gate_bwd_args& p = pm.a[mix];
     const int v = blockIdx.x * 256 + threadIdx.x;
     const int t = blockIdx.y;
-    const int b = blockIdx.z;
+    const int b = blockIdx.z - mix * pm.a[0].batch;
     if (v * VEC >= p.dim) return;
     const int64_t c = (int64_t)v * VEC;
     alignas(16) T dyv[VEC], zv[VEC], pv[VEC], gv[VEC], dzv[VEC];
@@ -163,12 +169,14 @@ static int launch_gate_bwd(const dm_gate_bwd_args& a, hipStream_t st) {
     auto al = [&](const void* ptr, int64_t sb, int64_t sl) { return (uintptr_t)ptr % 16 == 0 && sb % VECMAX == 0 && sl % VECMAX == 0; };
     const bool vec_ok = a.dim % VECMAX == 0 && al(a.dy, a.dy_sb, a.dy_sl) && al(a.z, a.z_sb, a.z_sl) && al(a.pre, a.p_sb, a.p_sl) &&
                         al(a.g, a.g_sb, a.g_sl) && al(a.dz, a.dz_sb, a.dz_sl);
+    unsigned gz;
+    const mix_args<dm_gate_bwd_args> m = mix_make(a, gz);
     if (vec_ok) {
-        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch);
-        hipLaunchKernelGGL((gate_bwd_kernel<T, VECMAX>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.dim / VECMAX + 255) / 256, a.seqlen, a.batch * gz);
+        hipLaunchKernelGGL((gate_bwd_kernel<T, VECMAX>), grid, dim3(256), 0, st, m);
     } else {
-        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch);
-        hipLaunchKernelGGL((gate_bwd_kernel<T, 1>), grid, dim3(256), 0, st, a);
+        dim3 grid((a.dim + 255) / 256, a.seqlen, a.batch * gz);
+        hipLaunchKernelGGL((gate_bwd_kernel<T, 1>), grid, dim3(256), 0, st, m);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_gate_bwd: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
@@ -182,7 +190,7 @@ extern "C" int dm_gate_bwd(const dm_gate_bwd_args* args, void* stream) {
     const dm_gate_bwd_args& a = *args;
     if (!a.dy || !a.z || !a.pre || !a.g || !a.dz) { set_error("dm_gate_bwd: null tensor pointer"); return DM_ERR_ARG; }
     if (a.batch <= 0 || a.seqlen <= 0 || a.dim <= 0) { set_error("dm_gate_bwd: non-positive size"); return DM_ERR_ARG; }
-    if (a.batch > 65535 || a.seqlen > 65535) { set_error("dm_gate_bwd: batch/seqlen > 65535"); return DM_ERR_ARG; }
+    if (a.batch * DM_MAX_MIX > 65535 || a.seqlen > 65535) { set_error("dm_gate_bwd: batch > 32767 or seqlen > 65535"); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     switch (a.io_dtype) {
         case DM_F32: return launch_gate_bwd<float>(a, st);
@@ -199,7 +207,11 @@ extern "C" int dm_gate_bwd(const dm_gate_bwd_args* args, void* stream) {
 // ------------------------------------------------------------------------------------------------------------
 namespace dm {
 constexpr int CS_WAVES = 16;
-__global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+__global__ __launch_bounds__(64 * CS_WAVES) void colsum_kernel(const mix_args<dm_colsum_args> pm) {
+    const dm_colsum_args& pa = pm.a[blockIdx.z];
+    const float* __restrict__ in = pa.in;
+    float* __restrict__ out = pa.out;
+    const int R = (int)pa.rows, C = (int)pa.cols;
     __shared__ float lds[CS_WAVES][WAVE * 4];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -238,8 +250,10 @@ extern "C" int dm_colsum_f32(const dm_colsum_args* args, void* stream) {
         set_error("dm_colsum_f32: rows, cols must be positive and cols a multiple of 4"); return DM_ERR_ARG;
     }
     if (((uintptr_t)in % 16) || ((uintptr_t)out % 16)) { set_error("dm_colsum_f32: tensors must be 16-byte aligned"); return DM_ERR_LAYOUT; }
-    dim3 grid((unsigned)((cols / 4 + WAVE - 1) / WAVE));
-    hipLaunchKernelGGL(colsum_kernel, grid, dim3(64 * CS_WAVES), 0, (hipStream_t)stream, in, out, (int)rows, (int)cols);
+    unsigned gz;
+    const mix_args<dm_colsum_args> m = mix_make(*args, gz);
+    dim3 grid((unsigned)((cols / 4 + WAVE - 1) / WAVE), 1, gz);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(64 * CS_WAVES), 0, (hipStream_t)stream, m);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_colsum_f32: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
@@ -251,7 +265,8 @@ extern "C" int dm_colsum_f32(const dm_colsum_args* args, void* stream) {
 // ------------------------------------------------------------------------------------------------------------
 namespace dm {
 template <typename TO>
-__global__ __launch_bounds__(256) void sum_partials_kernel(const dm_sum_partials_args p) {
+__global__ __launch_bounds__(256) void sum_partials_kernel(const mix_args<dm_sum_partials_args> pm) {
+    const dm_sum_partials_args& p = pm.a[blockIdx.z];
     const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;           // (row, 4-column group)
     const int cg = p.cols / 4;
     if (q >= p.rows * cg) return;
@@ -278,15 +293,60 @@ extern "C" int dm_sum_partials(const dm_sum_partials_args* args, void* stream) {
     if (((uintptr_t)a.in % 16) || ((uintptr_t)a.out % (4 * es)) || (a.out_sr % 4)) { set_error("dm_sum_partials: in must be 16-byte aligned, out rows aligned to 4 elements"); return DM_ERR_LAYOUT; }
     const int64_t n = a.rows * (a.cols / 4);
     if ((n + 255) / 256 > 0x7fffffff) { set_error("dm_sum_partials: too many rows"); return DM_ERR_ARG; }
-    dim3 grid((unsigned)((n + 255) / 256));
+    unsigned gz;
+    const mix_args<dm_sum_partials_args> m = mix_make(a, gz);
+    dim3 grid((unsigned)((n + 255) / 256), 1, gz);
     hipStream_t st = (hipStream_t)stream;
     switch (a.out_dtype) {
-        case DM_F32: hipLaunchKernelGGL((sum_partials_kernel<float>), grid, dim3(256), 0, st, a); break;
-        case DM_BF16: hipLaunchKernelGGL((sum_partials_kernel<bf16_t>), grid, dim3(256), 0, st, a); break;
-        case DM_F16: hipLaunchKernelGGL((sum_partials_kernel<f16_t>), grid, dim3(256), 0, st, a); break;
+        case DM_F32: hipLaunchKernelGGL((sum_partials_kernel<float>), grid, dim3(256), 0, st, m); break;
+        case DM_BF16: hipLaunchKernelGGL((sum_partials_kernel<bf16_t>), grid, dim3(256), 0, st, m); break;
+        case DM_F16: hipLaunchKernelGGL((sum_partials_kernel<f16_t>), grid, dim3(256), 0, st, m); break;
         default: set_error("dm_sum_partials: bad out_dtype %d", a.out_dtype); return DM_ERR_DTYPE;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error("dm_sum_partials: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
     return DM_OK;
+}
+
+// ---- n congruent launches in one (the two mixers of a block at small batch; see dm_common.h mix_args) ------------------------
+static inline bool same_align16(const void* x, const void* y) { return (((uintptr_t)x ^ (uintptr_t)y) & 15) == 0; }
+
+extern "C" int dm_token_merge_n(const dm_merge_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_token_merge_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_merge_args* a) { return dm_token_merge(a, stream); },
+                        [](const dm_merge_args& x, const dm_merge_args& y) {
+                            return same_align16(x.in, y.in) && same_align16(x.out, y.out) && same_align16(x.gate, y.gate) &&
+                                   same_align16(x.pre, y.pre) &&          // the 16-byte form is chosen per pointer
+                                   mix_congruent(x, y, &dm_merge_args::in, &dm_merge_args::row_index, &dm_merge_args::out,
+                                                 &dm_merge_args::gate, &dm_merge_args::pre);
+                        });
+}
+
+extern "C" int dm_gate_bwd_n(const dm_gate_bwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_gate_bwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_gate_bwd_args* a) { return dm_gate_bwd(a, stream); },
+                        [](const dm_gate_bwd_args& x, const dm_gate_bwd_args& y) {
+                            return same_align16(x.dy, y.dy) && same_align16(x.z, y.z) && same_align16(x.pre, y.pre) &&
+                                   same_align16(x.g, y.g) && same_align16(x.dz, y.dz) &&
+                                   mix_congruent(x, y, &dm_gate_bwd_args::dy, &dm_gate_bwd_args::z, &dm_gate_bwd_args::pre,
+                                                 &dm_gate_bwd_args::g, &dm_gate_bwd_args::dz);
+                        });
+}
+
+extern "C" int dm_colsum_f32_n(const dm_colsum_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_colsum_f32_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_colsum_args* a) { return dm_colsum_f32(a, stream); },
+                        [](const dm_colsum_args& x, const dm_colsum_args& y) { return mix_congruent(x, y, &dm_colsum_args::in, &dm_colsum_args::out); });
+}
+
+extern "C" int dm_sum_partials_n(const dm_sum_partials_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_sum_partials_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_sum_partials_args* a) { return dm_sum_partials(a, stream); },
+                        [](const dm_sum_partials_args& x, const dm_sum_partials_args& y) {
+                            return mix_congruent(x, y, &dm_sum_partials_args::in, &dm_sum_partials_args::out);
+                        });
 }

@@ -46,3 +46,16 @@ extern "C" int dm_selective_scan_bwd(const dm_scan_bwd_args* args, void* stream)
         default: set_error("dm_selective_scan_bwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
     }
 }
+
+// n congruent launches in one when the shape selects the small-launch (chunk-parallel) kernel (dm_common.h mix_args)
+extern "C" int dm_selective_scan_bwd_n(const dm_scan_bwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0) { set_error("dm_selective_scan_bwd_n: null args / n <= 0"); return DM_ERR_ARG; }
+    return mix_launch_n(args, n, [&](const dm_scan_bwd_args* a) { return dm_selective_scan_bwd(a, stream); },
+                        [](const dm_scan_bwd_args& x, const dm_scan_bwd_args& y) {
+                            using A = dm_scan_bwd_args;
+                            return mix_congruent(x, y, &A::u, &A::delta, &A::z, &A::dout, &A::B, &A::C, &A::A, &A::D, &A::delta_bias,
+                                                 &A::z_row_index, &A::out_row_index, &A::ckpt, &A::du, &A::ddelta, &A::dz,
+                                                 &A::dBC_partial, &A::dA_partial, &A::dD_partial, &A::dbias_partial);
+                        });
+}

@@ -34,7 +34,8 @@ __device__ __forceinline__ float row_sum16(float x) {
 }
 
 template <typename T, typename TBC, bool HAS_Z, bool IDX, int DMODE, int NW, int LC, bool ASH = false>   // DMODE: scan_bwd_impl.h
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void scan_bwd_chunked_kernel(const dm_scan_bwd_args p) {
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2))) void scan_bwd_chunked_kernel(const mix_args<dm_scan_bwd_args> pm) {
+    const dm_scan_bwd_args& p = pm.a[blockIdx.z];      // grid.z = congruent launches sharing this one (the two mixers of a block)
     constexpr int N = 16, NPL = N / 2, SUB = BWD_SUB, M = 2 * N, NSUB = LC / SUB;
     constexpr int ES = (int)sizeof(T);
     constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value;
@@ -391,22 +392,24 @@ static inline int bwd_chunked_lc(int nseq, int dim, int seqlen, int dstate, int 
 
 template <typename T, typename TBC, bool HAS_Z, bool IDX, int LC>
 static void launch_bwd_chunked3(const dm_scan_bwd_args& a, hipStream_t st) {
-    dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq), block(WAVE * BWD_CHUNKED_NW);
+    unsigned gz;
+    const mix_args<dm_scan_bwd_args> m = mix_make(a, gz);
+    dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq, gz), block(WAVE * BWD_CHUNKED_NW);
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
     if constexpr (HAS_Z && IDX) {
         if ((a.flags & DM_FLAG_A_SHARED) && sp) {
-            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, true, true, 1, BWD_CHUNKED_NW, LC, true>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, true, true, 1, BWD_CHUNKED_NW, LC, true>), grid, block, 0, st, m);
             return;
         }
     }
     if constexpr (!HAS_Z && IDX) {                    // hoisted gate + hoisted softplus (the DiffMa mixer's call pattern)
         if (a.flags & DM_FLAG_DELTA_ACTIVATED) {
-            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, false, true, 2, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, false, true, 2, BWD_CHUNKED_NW, LC>), grid, block, 0, st, m);
             return;
         }
     }
-    if (sp) hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 1, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 0, BWD_CHUNKED_NW, LC>), grid, block, 0, st, a);
+    if (sp) hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 1, BWD_CHUNKED_NW, LC>), grid, block, 0, st, m);
+    else hipLaunchKernelGGL((scan_bwd_chunked_kernel<T, TBC, HAS_Z, IDX, 0, BWD_CHUNKED_NW, LC>), grid, block, 0, st, m);
 }
 
 template <typename T, typename TBC>

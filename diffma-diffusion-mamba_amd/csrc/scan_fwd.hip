@@ -8,14 +8,18 @@ int scan_fwd_bf16(const dm_scan_fwd_args& a, hipStream_t st);
 int scan_fwd_f16(const dm_scan_fwd_args& a, hipStream_t st);
 }  // namespace dm
 
-extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream) {
-    using namespace dm;
-    if (!args) { set_error("dm_selective_scan_fwd: null args"); return DM_ERR_ARG; }
-    dm_scan_fwd_args a = *args;
+static dm_scan_fwd_args scan_fwd_normalised(dm_scan_fwd_args a) {
     if (a.flags & DM_FLAG_DELTA_ACTIVATED) {          // delta already holds softplus(raw + bias): the forward uses it as is
         a.flags &= ~(DM_FLAG_DELTA_ACTIVATED | DM_FLAG_DELTA_SOFTPLUS);
         a.delta_bias = nullptr;
     }
+    return a;
+}
+
+extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_selective_scan_fwd: null args"); return DM_ERR_ARG; }
+    const dm_scan_fwd_args a = scan_fwd_normalised(*args);
     if (!a.u || !a.delta || !a.out || !a.A || !a.B || !a.C) {
         set_error("dm_selective_scan_fwd: null tensor pointer"); return DM_ERR_ARG;
     }
@@ -56,4 +60,19 @@ extern "C" int dm_selective_scan_fwd(const dm_scan_fwd_args* args, void* stream)
         case DM_F16: return scan_fwd_f16(a, st);
         default: set_error("dm_selective_scan_fwd: bad io_dtype %d", a.io_dtype); return DM_ERR_DTYPE;
     }
+}
+
+// n congruent launches in one when the shape selects the small-launch (chunk-parallel) kernel, which takes an array of argument
+// structs (dm_common.h mix_args); the sequential kernel runs them one after the other.
+extern "C" int dm_selective_scan_fwd_n(const dm_scan_fwd_args* args, int n, void* stream) {
+    using namespace dm;
+    if (!args || n <= 0 || n > 16) { set_error("dm_selective_scan_fwd_n: null args / n not in 1..16"); return DM_ERR_ARG; }
+    dm_scan_fwd_args norm[16];
+    for (int i = 0; i < n; ++i) norm[i] = scan_fwd_normalised(args[i]);
+    return mix_launch_n(norm, n, [&](const dm_scan_fwd_args* a) { return dm_selective_scan_fwd(a, stream); },
+                        [](const dm_scan_fwd_args& x, const dm_scan_fwd_args& y) {
+                            using A = dm_scan_fwd_args;
+                            return mix_congruent(x, y, &A::u, &A::delta, &A::z, &A::out, &A::B, &A::C, &A::A, &A::D, &A::delta_bias,
+                                                 &A::z_row_index, &A::out_row_index, &A::ckpt, &A::last_state);
+                        });
 }

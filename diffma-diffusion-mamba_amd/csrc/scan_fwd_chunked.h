@@ -18,7 +18,8 @@
 namespace dm {
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX, bool SOFTPLUS, int NW, int LC, bool ASH = false, bool CKPT = false>
-__global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const dm_scan_fwd_args p) {
+__global__ __launch_bounds__(64 * NW) void scan_fwd_chunked_kernel(const mix_args<dm_scan_fwd_args> pm) {
+    const dm_scan_fwd_args& p = pm.a[blockIdx.z];      // grid.z = congruent launches sharing this one (the two mixers of a block)
     constexpr int NP = N / 2;
     constexpr int ES = (int)sizeof(T);
     __shared__ __attribute__((aligned(16))) float bc_lds[NW][LC][2 * N];      // [B row | C row] of every step of the wave's chunk
@@ -183,27 +184,29 @@ static inline bool use_chunked_fwd(const dm_scan_fwd_args& a) {
 
 template <typename T, typename TBC, bool HAS_Z, bool IDX>
 static void launch_fwd_chunked2(const dm_scan_fwd_args& a, hipStream_t st) {
-    dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq), block(WAVE * CHUNKED_NW);
+    unsigned gz;
+    const mix_args<dm_scan_fwd_args> m = mix_make(a, gz);
+    dim3 grid((a.dim + WAVE - 1) / WAVE, a.nseq, gz), block(WAVE * CHUNKED_NW);
     const bool sp = (a.flags & DM_FLAG_DELTA_SOFTPLUS) != 0;
     if constexpr (HAS_Z && IDX) {                   // the model's call pattern: also built with checkpoints (small-batch training)
         if ((a.flags & DM_FLAG_A_SHARED) && sp) {
-            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, false>), grid, block, 0, st, a);
+            if (a.ckpt) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, true>), grid, block, 0, st, m);
+            else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, true, false>), grid, block, 0, st, m);
             return;
         }
         if (a.ckpt && sp) {
-            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, true, true, true, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, m);
             return;
         }
     }
     if constexpr (!HAS_Z && IDX) {                  // hoisted gate + hoisted softplus (DM_FLAG_DELTA_ACTIVATED arrives here as "no softplus, no bias")
         if (a.ckpt && !sp) {
-            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, false, true, false, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, a);
+            hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, false, true, false, CHUNKED_NW, CHUNKED_LC, false, true>), grid, block, 0, st, m);
             return;
         }
     }
-    if (sp) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, true, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, false, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, a);
+    if (sp) hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, true, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, m);
+    else hipLaunchKernelGGL((scan_fwd_chunked_kernel<T, TBC, 16, HAS_Z, IDX, false, CHUNKED_NW, CHUNKED_LC>), grid, block, 0, st, m);
 }
 
 template <typename T, typename TBC>

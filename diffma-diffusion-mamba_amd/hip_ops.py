@@ -79,14 +79,98 @@ def set_timer(timer):
     return prev
 
 
+class paired:
+    """Context manager that makes the two mixers of a DiffMa block share their kernel launches (reference block/mamba_block.py:107-108
+    runs them one after the other; at the reference's own batch -- config/brain.yaml, one sample per GPU -- a step is bound by the
+    number of launches).  Inside the block the C-ABI launches of this module are QUEUED instead of issued; the caller runs the same
+    wrapper calls first for mixer 0, then for mixer 1; at exit launch i of mixer 0 and launch i of mixer 1 go out as ONE call of the
+    kernel's `_n` entry point (include/diffma_hip.h, ABI 25), which puts congruent launches into one grid (blockIdx.z picks the
+    argument struct) and falls back to two launches otherwise.  Results are bit-identical to the unpaired calls.
+    Rules for the code inside: only wrapper calls, allocations and views -- no torch arithmetic on their outputs (they have not
+    been computed yet); a wrapper that has to fall back to torch arithmetic calls `_pair_flush()` first, which issues everything
+    queued so far one by one and turns the rest of the block into immediate launches.  Every tensor whose pointer went into a
+    queued argument struct is kept alive until the launch (`_ptr`)."""
+
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+        self.queue, self.keep, self.broken, self.mark = [], [], False, None
+
+    def __enter__(self):
+        global _PAIR
+        if self.enabled:
+            if _PAIR is not None:
+                raise RuntimeError("hip_ops.paired() does not nest")
+            _PAIR = self
+        return self
+
+    def second(self):
+        """Call between the first and the second mixer's wrapper calls."""
+        self.mark = len(self.queue)
+
+    def __exit__(self, et, ev, tb):
+        global _PAIR
+        if not self.enabled:
+            return False
+        _PAIR = None
+        if et is None:
+            self.flush(pairwise=True)
+        self.queue, self.keep = [], []
+        return False
+
+    def flush(self, pairwise=False):
+        q, self.queue = self.queue, []
+        k = self.mark
+        if pairwise and not self.broken and k is not None and len(q) == 2 * k and all(q[i][0] == q[i + k][0] for i in range(k)):
+            for i in range(k):
+                name, a0, tensor, nbytes, design = q[i]
+                _issue(name, [a0, q[i + k][1]], tensor, nbytes + q[i + k][3], None if design is None else design + (q[i + k][4] or 0))
+        else:
+            for name, a, tensor, nbytes, design in q:
+                _issue(name, [a], tensor, nbytes, design)
+        self.keep = []
+        self.mark = None
+
+
+_PAIR = None
+
+
+def _pair_flush():
+    """A wrapper is about to do torch arithmetic on launch outputs: issue what is queued (unpaired) and stop queueing."""
+    if _PAIR is not None:
+        _PAIR.flush()
+        _PAIR.broken = True
+
+
+_DEBUG_SYNC = os.environ.get("DIFFMA_DEBUG_SYNC", "0") == "1"      # developer aid: synchronise and name every C-ABI launch
+
+
+def _issue(name, arg_list, tensor, nbytes, design_bytes):
+    if _DEBUG_SYNC:
+        print(f"[hip_ops] {name} x{len(arg_list)}", flush=True)
+    with torch.cuda.device(tensor.device):
+        if len(arg_list) == 1:
+            fn = lambda: _lib.call(name, arg_list[0], _stream(tensor))
+        elif _lib.has_n(name):
+            fn = lambda: _lib.call_n(name, arg_list, _stream(tensor))
+        else:
+            def fn():
+                for a in arg_list:
+                    _lib.call(name, a, _stream(tensor))
+        if _TIMER is None:
+            fn()
+        else:
+            _TIMER.launch(name, nbytes, fn, design_bytes)
+        if _DEBUG_SYNC:
+            torch.cuda.synchronize()
+
+
 def _launch(name, args, tensor, nbytes, design_bytes=None):
     """nbytes: ALGORITHMIC bytes of the launch (SURVEY.md 8d: what any implementation of the operator must move);
     design_bytes: the bytes THIS implementation moves by design (algorithmic + checkpoints + partial rows), if different."""
-    with torch.cuda.device(tensor.device):
-        if _TIMER is None:
-            _lib.call(name, args, _stream(tensor))
-        else:
-            _TIMER.launch(name, nbytes, lambda: _lib.call(name, args, _stream(tensor)), design_bytes)
+    if _PAIR is not None and not _PAIR.broken:
+        _PAIR.queue.append((name, args, tensor, nbytes, design_bytes))
+        return
+    _issue(name, [args], tensor, nbytes, design_bytes)
 
 
 def dtype_code(t: torch.Tensor) -> int:
@@ -109,7 +193,11 @@ def _stream(t: torch.Tensor) -> int:
 
 
 def _ptr(t):
-    return 0 if t is None else t.data_ptr()
+    if t is None:
+        return 0
+    if _PAIR is not None:
+        _PAIR.keep.append(t)           # the launch is deferred: the tensor must outlive the wrapper call that named it
+    return t.data_ptr()
 
 
 def _f32c(t):
@@ -315,6 +403,7 @@ def sum_partials(parts, out):
     es = out.element_size()
     if (o2 is None or C % 4 or not parts.is_contiguous() or parts.dtype != torch.float32 or out.dtype not in _DT
             or o2.data_ptr() % (4 * es) or o2.stride(0) % 4):
+        _pair_flush()
         out.copy_(parts.sum(dim=1).view(out.shape))
         return out
     a = dm_sum_partials_args()
@@ -334,6 +423,7 @@ def colsum(x, small=False):
     """x [R, C] fp32 contiguous -> [C] = x.sum(0) (dm_colsum_f32: ATen's outer-dimension reduction is 4x off HBM speed here)."""
     R, C = x.shape
     if C % 4 != 0 or not x.is_contiguous() or x.dtype != torch.float32 or (small and not _COLSUM_SMALL):
+        _pair_flush()
         return x.sum(0)
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
     a = dm_colsum_args()
@@ -669,8 +759,11 @@ def ln_mod_fwd(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
     _require_gpu(x, x2, gamma, beta, shift, scale, mask)
     a, Bsz, L, C1, C2 = _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype)
     C = C1 + C2
-    y1 = torch.empty((Bsz, L, C), dtype=y_dtype, device=x.device)
-    y2 = torch.empty_like(y1) if mask is not None else None
+    if mask is not None:        # the two halves of ONE buffer: the paired mixers' in_proj reads them as a batch of 2 without a copy
+        y12 = torch.empty((2, Bsz, L, C), dtype=y_dtype, device=x.device)
+        y1, y2 = y12[0], y12[1]
+    else:
+        y1, y2 = torch.empty((Bsz, L, C), dtype=y_dtype, device=x.device), None
     stats = torch.empty((Bsz * L, 2), dtype=torch.float32, device=x.device)
     a.y1, a.y2, a.stats = _ptr(y1), _ptr(y2), _ptr(stats)
     esz = x.element_size()
@@ -729,7 +822,11 @@ def blend_bwd(g, xs, ws, a_row, gate):
     """Returns (dxs, dws, da [B,L,1], dgate [B,C] fp32)."""
     _require_gpu(g, xs, ws, a_row, gate)
     a, Bsz, L, C = _blend_args(g, xs, ws, a_row, gate)
-    dxs, dws = torch.empty_like(xs), torch.empty_like(ws)
+    if xs.shape == ws.shape and xs.dtype == ws.dtype and xs.is_contiguous() and ws.is_contiguous():
+        d2 = torch.empty((2,) + tuple(xs.shape), dtype=xs.dtype, device=xs.device)      # halves of one buffer: the paired mixers'
+        dxs, dws = d2[0], d2[1]                                                          # out_proj backward reads them as a batch of 2
+    else:
+        dxs, dws = torch.empty_like(xs), torch.empty_like(ws)
     da = torch.empty_like(a_row)
     bpb = (L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK
     part = torch.empty((Bsz, bpb, C), dtype=torch.float32, device=g.device)

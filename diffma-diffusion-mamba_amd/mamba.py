@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .selective_scan_interface import linear_splitk, spiral_ssm
+from .selective_scan_interface import linear_pair, linear_splitk, spiral_ssm, spiral_ssm_pair, spiral_ssm_pair_supported
 from .tools import efficient_scan_tokens
 
 
@@ -111,20 +111,24 @@ class Mamba(nn.Module):
         if hidden_states.shape[1] != self.scan_index.shape[1]:
             raise ValueError(f"sequence length {hidden_states.shape[1]} != spiral table length {self.scan_index.shape[1]}")
         xz = linear_splitk(hidden_states, self.in_proj.weight, self.in_proj.bias)      # [B, L, 2*Din] token-major
-        A = self.__dict__.pop("_A_step", None)       # made for all mixers at once by step_prep.prepare (DiffMa.forward), used once
-        if A is not None and A.device == xz.device and torch.is_grad_enabled():
-            pass
-        elif torch.is_grad_enabled() or (xz.is_cuda and torch.cuda.is_current_stream_capturing()):
-            A = -torch.exp(self.A_log.float())       # inside a capture A is recomputed IN the graph: replays follow A_log
-        else:                                        # inference: A only changes when A_log does (two tiny kernels per call otherwise)
-            cache = getattr(self, "_A_cache", None)  # (hipGraph replays of an optimizer do not bump _version: GraphedTrainStep drops the cache)
-            if cache is None or cache[0] != self.A_log._version or cache[1].device != self.A_log.device:
-                cache = (self.A_log._version, -torch.exp(self.A_log.detach().float()))
-                self._A_cache = cache
-            A = cache[1]
+        A = self._A_now(xz)
         y = spiral_ssm(xz, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight,
                        self.dt_proj.bias, A, self.D, self.scan_index)
         return linear_splitk(y.to(xz.dtype), self.out_proj.weight, self.out_proj.bias)
+
+    def _A_now(self, like):
+        """A = -exp(A_log) for this call: the tensor step_prep made for all mixers at once, else computed / cached here."""
+        A = self.__dict__.pop("_A_step", None)       # made for all mixers at once by step_prep.prepare (DiffMa.forward), used once
+        if A is not None and A.device == like.device and torch.is_grad_enabled():
+            return A
+        if torch.is_grad_enabled() or (like.is_cuda and torch.cuda.is_current_stream_capturing()):
+            return -torch.exp(self.A_log.float())    # inside a capture A is recomputed IN the graph: replays follow A_log
+        # inference: A only changes when A_log does (two tiny kernels per call otherwise)
+        cache = getattr(self, "_A_cache", None)      # (hipGraph replays of an optimizer do not bump _version: GraphedTrainStep drops the cache)
+        if cache is None or cache[0] != self.A_log._version or cache[1].device != self.A_log.device:
+            cache = (self.A_log._version, -torch.exp(self.A_log.detach().float()))
+            self._A_cache = cache
+        return cache[1]
 
     def _forward_baseline(self, hidden_states, scan_type):
         """The ZigMa / ViM / VMamba / EfficientVMamba token orders (reference block/mamba.py:357-401) on the fused operator.
@@ -156,3 +160,19 @@ class Mamba(nn.Module):
         out = proj(ssm(sub.contiguous()))                          # [4B, L/4, d_model]
         out = out.view(4, Bsz, L4, -1).transpose(0, 1).reshape(Bsz, L, -1)
         return out[:, inv]
+
+
+def forward_pair(mix0: Mamba, mix1: Mamba, x0, x1):
+    """(mix0(x0, 'spiral'), mix1(x1, 'spiral')) -- the two mixers of a DiffMa block (reference block/mamba_block.py:107-108) -- with
+    every stage launched once for both when the call pattern allows it (selective_scan_interface._SpiralSSMPairFn), else one after
+    the other.  Same arithmetic per mixer either way."""
+    if not (isinstance(mix0, Mamba) and isinstance(mix1, Mamba) and x0.is_cuda and x0.shape == x1.shape and x0.dtype == x1.dtype
+            and mix0.in_proj.bias is None and mix1.in_proj.bias is None and mix0.out_proj.bias is None and mix1.out_proj.bias is None
+            and mix0.in_proj.weight.shape == mix1.in_proj.weight.shape and x0.shape[1] == mix0.scan_index.shape[1]):
+        return mix0(x0, "spiral"), mix1(x1, "spiral")
+    dt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x0.dtype
+    if not spiral_ssm_pair_supported(x0.shape[0], x0.shape[1], dt, mix0, mix1):
+        return mix0(x0, "spiral"), mix1(x1, "spiral")
+    xz0, xz1 = linear_pair(x0, x1, mix0.in_proj.weight, mix1.in_proj.weight)          # [B, L, 2*Din] each, halves of one buffer
+    y0, y1 = spiral_ssm_pair(xz0, xz1, mix0, mix1, mix0._A_now(xz0), mix1._A_now(xz1))
+    return linear_pair(y0, y1, mix0.out_proj.weight, mix1.out_proj.weight)

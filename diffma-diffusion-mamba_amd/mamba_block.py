@@ -14,8 +14,29 @@ import torch
 import torch.nn as nn
 
 from . import block_ops, hip_ops
-from .mamba import Mamba
+from .mamba import Mamba, forward_pair
 from .selective_scan_interface import GemmChain, linear_splitk
+
+
+_SILU_ONCE = [None]
+
+
+def _silu_once(c, dtype):
+    """SiLU(c) in the activation dtype, computed ONCE per conditioning tensor: every block of the denoiser applies the same
+    SiLU to the same `c` (reference block/mamba_block.py:82-85,101: adaLN_modulation = Sequential(SiLU, Linear)), which eager
+    execution repeats depth times forward and backward (SiLU, cast, cast, SiLU') -- at one sample per GPU those are launches the
+    step is made of.  The blocks' gradient contributions are added by autograd.  Keyed on the tensor object and its version."""
+    import weakref
+
+    ent = _SILU_ONCE[0]
+    grad = torch.is_grad_enabled()
+    if ent is not None and ent[0]() is c and ent[1] == c._version and ent[2] == dtype and ent[3] == grad:
+        return ent[4]
+    out = torch.nn.functional.silu(c)
+    if out.dtype != dtype:
+        out = out.to(dtype)
+    _SILU_ONCE[0] = (weakref.ref(c), c._version, dtype, grad, out)
+    return out
 
 
 def modulate(x, shift, scale):
@@ -88,6 +109,8 @@ class Spiral_MambaBlock(nn.Module):
 
     def _mixers(self, x_ssm, w_ssm):
         if not (self.overlap_mixers and x_ssm.is_cuda):
+            if isinstance(self.mamba1, Mamba):           # small launches: every stage once for both mixers (mamba.forward_pair)
+                return forward_pair(self.mamba1, self.mamba2, x_ssm, w_ssm)
             return self.mamba1(x_ssm, "spiral"), self.mamba2(w_ssm, "spiral")
         main = torch.cuda.current_stream(x_ssm.device)
         side = self._side_stream(x_ssm.device)
@@ -107,7 +130,14 @@ class Spiral_MambaBlock(nn.Module):
         return x_ssm, w_ssm
 
     def forward(self, x, c, w):
-        shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
+        if self.fused_elementwise and x.is_cuda:
+            # adaLN through linear_splitk: its 16-bit weight / bias copies come from the step's foreach cast (step_prep) instead of two
+            # cast launches per block, and the weight gradient leaves its GEMM in fp32
+            ada = self.adaLN_modulation
+            act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else c.dtype
+            shift, scale, gate = linear_splitk(_silu_once(c, act), ada[1].weight, ada[1].bias).chunk(3, dim=1)
+        else:
+            shift, scale, gate = self.adaLN_modulation(c).chunk(3, dim=1)
         if self.fused_elementwise and x.is_cuda:
             act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
             block_ops.set_output_dtype(act)

@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from . import hip_ops
-from .step_prep import cast_weight
+from .step_prep import cast_weight, stacked_pair
 
 
 def _to_token_major(t: torch.Tensor) -> torch.Tensor:
@@ -201,7 +201,9 @@ def _tn_splitk_impl(a, b):
         return t.as_strided((C, M // C, t.shape[1]), (M // C * t.stride(0), t.stride(0), 1))
 
     for C in (64, 32, 16, 8):
-        if M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23) and a.stride(1) == 1 and b.stride(1) == 1:
+        # (below ~12k rows one GEMM is as fast as the slab product + its sum, and it is one launch instead of two: the small-batch step
+        #  is made of launches)
+        if M >= 12288 and M % C == 0 and M // C >= 256 and C * a.shape[1] * b.shape[1] <= (1 << 23) and a.stride(1) == 1 and b.stride(1) == 1:
             return torch.bmm(slabs(a, C).transpose(1, 2), slabs(b, C)).sum(0, dtype=torch.float32)      # the cast is fused into the reduction
     return _mm_f32(a.t(), b)
 
@@ -217,7 +219,7 @@ class _LinearSplitKFn(torch.autograd.Function):
         wc = cast_weight(weight, dt_)                    # the step's shadow copy when current (step_prep), else a cast
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
-        return GemmChain.run(F.linear, xc, wc, None if bias is None else bias.to(dt_))
+        return GemmChain.run(F.linear, xc, wc, None if bias is None else cast_weight(bias, dt_))
 
     @staticmethod
     def backward(ctx, dy):
@@ -367,6 +369,266 @@ class _SpiralSSMFn(torch.autograd.Function):
             hip_ops.token_merge(dz.view(ndir, Bsz, L, Din), out=dxz[..., Din:])
         return (dxz, dconv_w.to(conv_w.dtype).reshape(conv_w.shape), dconv_b.to(conv_b.dtype) if conv_b is not None else None,
                 dWx, dWdt, dbias.to(dt_bias.dtype), dA.to(A.dtype), dD.to(Dskip.dtype), None, None, None, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# The TWO mixers of a DiffMa block as one set of launches (reference block/mamba_block.py:107-108)
+# ------------------------------------------------------------------------------------------------
+# The reference runs mamba1(x_ssm) and mamba2(w_ssm) one after the other: same shapes, different weights and spiral tables.  Its own
+# configuration trains at ONE sample per GPU (config/brain.yaml:11), where a step is bound by the number of kernel launches (eager:
+# the host's launch rate; hipGraph: ~8 us of dispatch per node), not by what the kernels do.  The pair path issues every stage once
+# for both mixers: the projections as batched GEMMs over stacked weights, the kernels through hip_ops.paired() -> the `_n` entry
+# points of the C ABI (one grid, blockIdx.z picks the mixer).  Arithmetic per mixer is unchanged: kernels bit-identical, GEMMs to
+# library rounding.  Used for small launches only (below the fused conv + x_proj threshold); large batches gain nothing from it.
+PAIR_MIXERS = os.environ.get("DIFFMA_PAIR_MIXERS", "1") == "1"
+
+# How the pair path multiplies by the two mixers' projection weights.  "bmm": ONE batched GEMM per product -- issued with TunableOp's
+# first-use tuning switched off around the call: tuning these batch-2 shapes runs library candidates that fault (MI355X, ROCm 7.2:
+# memory access faults inside the tuning loop at [2, 4704, 1024] x [2, 1024, 64] and, at one sample per GPU, at the in_proj /
+# out_proj shapes -- tools/dbg_bmm.py); the library's default choice is safe, but for an unrecorded batched shape it costs host time
+# on every call, which an eager small-batch step is made of.  "mm": one plain GEMM per mixer (the products the unpaired path has
+# always issued, tuned and recorded).  "auto" (default): bmm inside a hipGraph capture, where host time is paid once, mm otherwise.
+PAIR_GEMM = os.environ.get("DIFFMA_PAIR_GEMM", "bmm")
+
+
+def _pair_use_bmm(t):
+    if PAIR_GEMM == "auto":
+        return t.is_cuda and torch.cuda.is_current_stream_capturing()
+    return PAIR_GEMM == "bmm"
+
+
+def _bmm_untuned(x, y, out_dtype=None):
+    tun = torch.cuda.tunable if x.is_cuda else None
+    was = tun is not None and tun.is_enabled() and tun.tuning_is_enabled()
+    if was:
+        tun.tuning_enable(False)
+    try:
+        if out_dtype is None or out_dtype == x.dtype:
+            return torch.bmm(x, y)
+        try:
+            return torch.bmm(x, y, out_dtype=out_dtype)
+        except (RuntimeError, NotImplementedError, TypeError):
+            return torch.bmm(x, y).to(out_dtype)
+    finally:
+        if was:
+            tun.tuning_enable(True)
+
+
+def _pair_matmul(x, y, out_dtype=None):
+    """x [2, P, Q] @ y [2, Q, R] -> [2, P, R]: one batched GEMM, or one GEMM per mixer (see PAIR_GEMM)."""
+    if _pair_use_bmm(x):
+        return GemmChain.run(_bmm_untuned, x, y, out_dtype)
+    if out_dtype == torch.float32 and x.dtype != torch.float32:
+        return (_mm_f32(x[0], y[0]), _mm_f32(x[1], y[1]))      # indexable like a [2, ...] tensor: the caller only takes [0] and [1]
+    out = torch.empty((2, x.shape[1], y.shape[2]), dtype=x.dtype, device=x.device)
+    for g in (0, 1):
+        GemmChain.run(torch.mm, x[g], y[g], out=out[g])
+    return out
+
+
+def _as_pair(a, b):
+    """[2, ...] tensor holding a and b: the shared buffer when they already are its two halves (no copy), else a stack."""
+    if (a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+            and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()):
+        return torch.as_strided(a, (2,) + tuple(a.shape), (a.numel(),) + tuple(a.stride()))
+    return torch.stack([a, b])
+
+
+class _LinearPairFn(torch.autograd.Function):
+    """(x0 @ W0^T, x1 @ W1^T) as ONE batched GEMM each way; bias-free (in_proj / out_proj of the mixers, block/mamba.py:259-261,315)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, W0, W1):
+        dev = x0.device.type
+        dt_ = torch.get_autocast_dtype(dev) if torch.is_autocast_enabled(dev) else x0.dtype
+        xp = _as_pair(x0 if x0.dtype == dt_ else x0.to(dt_), x1 if x1.dtype == dt_ else x1.to(dt_))       # [2, B, L, K]
+        Wst = stacked_pair(W0, W1, dt_)                                                                   # [2, N, K]
+        ctx.save_for_backward(xp, Wst)
+        ctx.meta = (x0.dtype, W0.dtype)
+        K = xp.shape[-1]
+        y = _pair_matmul(xp.view(2, -1, K), Wst.transpose(1, 2))                                          # [2, M, N]
+        y = y.view(2, *x0.shape[:-1], Wst.shape[1])
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        xp, Wst = ctx.saved_tensors
+        x_dt, w_dt = ctx.meta
+        with torch.autocast(device_type=xp.device.type, enabled=False):
+            N, K = Wst.shape[1], Wst.shape[2]
+            dy = _as_pair(dy0.contiguous() if dy0.dtype == xp.dtype else dy0.contiguous().to(xp.dtype),
+                          dy1.contiguous() if dy1.dtype == xp.dtype else dy1.contiguous().to(xp.dtype)).view(2, -1, N)
+            x2 = xp.view(2, -1, K)
+            dx = _pair_matmul(dy, Wst).view(xp.shape)
+            if dx.dtype != x_dt:
+                dx = dx.to(x_dt)
+            if _pair_use_bmm(dy):
+                dW = _pair_matmul(dy.transpose(1, 2), x2, torch.float32)                                   # [2, N, K] fp32
+            else:
+                dW = (_tn_splitk(dy[0], x2[0]), _tn_splitk(dy[1], x2[1]))                                  # the unpaired path's products
+            dW0, dW1 = (dW[0], dW[1]) if w_dt == torch.float32 else (dW[0].to(w_dt), dW[1].to(w_dt))
+        return dx[0], dx[1], dW0, dW1
+
+
+def linear_pair(x0, x1, W0, W1):
+    """(F.linear(x0, W0), F.linear(x1, W1)) for the two mixers of a block: one batched GEMM forward, two backward."""
+    return _LinearPairFn.apply(x0, x1, W0, W1)
+
+
+class _SpiralSSMPairFn(torch.autograd.Function):
+    """_SpiralSSMFn for the two mixers of a block at once (hoisted gate + hoisted softplus, 16-bit I/O, d_state 16, small launches):
+    xz0, xz1 [B, L, 2*Din] -> (y0, y1) [B, L, Din], every kernel stage launched once for both."""
+
+    @staticmethod
+    def forward(ctx, xz0, xz1, idx0, idx1, grad_on, cw0, cw1, cb0, cb1, Wx0, Wx1, Wdt0, Wdt1, b0, b1, A0, A1, D0, D1):
+        Bsz, L, D2 = xz0.shape
+        Din = D2 // 2
+        ndir = idx0.shape[0]
+        R, N = Wdt0.shape[1], A0.shape[1]
+        S, M = ndir * Bsz, ndir * Bsz * L
+        dt_, dev = xz0.dtype, xz0.device
+        need_grad = grad_on and any(ctx.needs_input_grad)
+        xz, idx = (xz0, xz1), (idx0, idx1)
+        cw, cb, bias, A, Dk = (cw0, cw1), (cb0, cb1), (b0, b1), (A0, A1), (D0, D1)
+        Wx_st, Wdt_st = stacked_pair(Wx0, Wx1, dt_), stacked_pair(Wdt0, Wdt1, dt_)       # [2, R+2N, Din], [2, Din, R]
+        xc = torch.empty((2, S, L, Din), dtype=dt_, device=dev)
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                hip_ops.gather_conv1d_fwd(xz[g][..., :Din], cw[g], cb[g], row_index=idx[g], ndir=ndir, silu=True, out=xc[g])
+        # x_proj stays one product per mixer: as a batch-2 GEMM its [M, 1024] x [1024, 64] shape makes TunableOp's first-use tuning
+        # run a library candidate that faults (MI355X, ROCm 7.2: memory access fault inside the tuning loop, tools/dbg_bmm.py);
+        # the plain products below are the ones the unpaired path has always issued
+        x_dbl = torch.empty((2, M, R + 2 * N), dtype=dt_, device=dev)
+        for g in (0, 1):
+            GemmChain.run(torch.mm, xc[g].view(M, Din), Wx_st[g].t(), out=x_dbl[g])
+        delta = [None, None]
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                delta[g] = hip_ops.dtproj_softplus_fwd(x_dbl[g], Wdt_st[g], bias[g]).view(S, L, Din)
+        ckpt = [hip_ops.alloc_scan_ckpt(S, L, N, Din, dt_, dev) if need_grad else None for _ in (0, 1)]
+        xd3 = x_dbl.view(2, S, L, R + 2 * N)
+        ydir = [None, None]
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                ydir[g] = hip_ops.scan_fwd(xc[g], delta[g], A[g], xd3[g][..., R:R + N], xd3[g][..., R + N:], Dk[g], None, bias[g], True,
+                                           z_row_index=idx[g], out_row_index=idx[g], batch_per_dir=Bsz, ckpt=ckpt[g], delta_activated=True)
+        y = torch.empty((2, Bsz, L, Din), dtype=dt_, device=dev)
+        pre = torch.empty((2, Bsz, L, Din), dtype=dt_, device=dev) if need_grad else None
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                hip_ops.token_merge(ydir[g].view(ndir, Bsz, L, Din), gate=xz[g][..., Din:], pre_out=None if pre is None else pre[g], out=y[g])
+        if need_grad:
+            ctx.save_for_backward(xz0, xz1, idx0, idx1, cw0, cw1, cb0, cb1, b0, b1, A0, A1, D0, D1, Wx_st, Wdt_st, xc, x_dbl,
+                                  delta[0], delta[1], ckpt[0], ckpt[1], pre)
+            ctx.meta = (Wx0.dtype, Wdt0.dtype)
+        return y[0], y[1]
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        (xz0, xz1, idx0, idx1, cw0, cw1, cb0, cb1, b0, b1, A0, A1, D0, D1, Wx_st, Wdt_st, xc, x_dbl, dl0, dl1, ck0, ck1, pre) = ctx.saved_tensors
+        wx_dt, wdt_dt = ctx.meta
+        Bsz, L, D2 = xz0.shape
+        Din = D2 // 2
+        ndir = idx0.shape[0]
+        R, N = Wdt_st.shape[2], A0.shape[1]
+        S, M = ndir * Bsz, ndir * Bsz * L
+        dt_, dev = xz0.dtype, xz0.device
+        xz, idx, delta, ckpt = (xz0, xz1), (idx0, idx1), (dl0, dl1), (ck0, ck1)
+        cw, cb, bias, A, Dk = (cw0, cw1), (cb0, cb1), (b0, b1), (A0, A1), (D0, D1)
+        dy = [t.contiguous() if t.dtype == dt_ else t.contiguous().to(dt_) for t in (dy0, dy1)]
+        dxz = torch.empty((2, Bsz, L, D2), dtype=dt_, device=dev)
+        dx_dbl = torch.empty((2, M, R + 2 * N), dtype=dt_, device=dev)
+        xd3 = x_dbl.view(2, S, L, R + 2 * N)
+        gate_g = [None, None]
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                gate_g[g], _ = hip_ops.gate_bwd(dy[g], xz[g][..., Din:], pre[g], dz_out=dxz[g][..., Din:])
+        du = torch.empty((2, S, L, Din), dtype=dt_, device=dev)
+        res = [None, None]
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                res[g] = hip_ops.scan_bwd(xc[g], delta[g], A[g], xd3[g][..., R:R + N], xd3[g][..., R + N:], Dk[g], None, bias[g], gate_g[g], ckpt[g],
+                                          True, z_row_index=idx[g], out_row_index=idx[g], batch_per_dir=Bsz, du_out=du[g],
+                                          dbc_out=dx_dbl[g].view(S, L, R + 2 * N)[..., R:], delta_activated=True)
+        ddelta = [res[g][1].view(M, Din) for g in (0, 1)]
+        dWdt = [None, None]
+        if hip_ops.dtproj_bwd_supported(ddelta[0], x_dbl[0], Wdt_st[0], dx_dbl[0]):
+            with hip_ops.paired() as pr:
+                for g in (0, 1):
+                    if g:
+                        pr.second()
+                    dWdt[g] = hip_ops.dtproj_bwd(ddelta[g], x_dbl[g], Wdt_st[g], dx_dbl[g])
+        else:
+            for g in (0, 1):
+                dx_dbl[g][:, :R] = GemmChain.run(torch.mm, ddelta[g], Wdt_st[g])
+                dWdt[g] = _tn_splitk(ddelta[g], x_dbl[g][:, :R])
+        dWx = [_tn_splitk(dx_dbl[g], xc[g].view(M, Din)) for g in (0, 1)]                   # [R+2N, Din] fp32 each (per mixer: see the forward)
+        for g in (0, 1):
+            GemmChain.run(du[g].view(M, Din).addmm_, dx_dbl[g], Wx_st[g])                   # d x~ = du + dx_dbl @ Wx, in place
+        dxc = du
+        cres = [None, None]
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                cres[g] = hip_ops.gather_conv1d_bwd(xz[g][..., :Din], cw[g], cb[g], dxc[g], row_index=idx[g], ndir=ndir, silu=True)
+        with hip_ops.paired() as pr:
+            for g in (0, 1):
+                if g:
+                    pr.second()
+                hip_ops.token_merge(cres[g][0].view(ndir, Bsz, L, Din), out=dxz[g][..., :Din])
+        out = [dxz[0], dxz[1], None, None, None]
+        per = lambda f: [f(0), f(1)]
+        out += per(lambda g: cres[g][1].to(cw[g].dtype).reshape(cw[g].shape))
+        out += per(lambda g: cres[g][2].to(cb[g].dtype) if cb[g] is not None else None)
+        out += per(lambda g: dWx[g] if dWx[g].dtype == wx_dt else dWx[g].to(wx_dt))
+        out += per(lambda g: dWdt[g] if dWdt[g].dtype == wdt_dt else dWdt[g].to(wdt_dt))
+        out += per(lambda g: res[g][7].to(bias[g].dtype))
+        out += per(lambda g: res[g][5].to(A[g].dtype))
+        out += per(lambda g: res[g][6].to(Dk[g].dtype))
+        return tuple(out)
+
+
+def spiral_ssm_pair_supported(Bsz, L, dtype, mix0, mix1):
+    """The call pattern the pair path is built for: two Mamba-1 mixers of equal shape on a ROCm device, 16-bit activations,
+    d_state 16, a conv with bias, and a launch small enough that the unfused conv / chunk-parallel scans serve it."""
+    if not (PAIR_MIXERS and HOIST_GATE and dtype in (torch.bfloat16, torch.float16)):
+        return False
+    idx0, idx1 = mix0.scan_index, mix1.scan_index
+    if not idx0.is_cuda or idx0.shape != idx1.shape or idx0.shape[0] < 2 or idx0.shape[1] != L:
+        return False
+    if mix0.A_log.shape != mix1.A_log.shape or mix0.A_log.shape[1] != 16 or mix0.conv1d.bias is None or mix1.conv1d.bias is None:
+        return False
+    if mix0.conv1d.weight.shape != mix1.conv1d.weight.shape or mix0.x_proj.weight.shape != mix1.x_proj.weight.shape:
+        return False
+    if idx0.shape[0] * Bsz >= hip_ops.XPROJ_FUSED_MIN_SEQS:
+        return False
+    Din, R = mix0.dt_proj.weight.shape
+    from . import _lib
+    code = {torch.bfloat16: _lib.DM_BF16, torch.float16: _lib.DM_F16}[dtype]
+    return bool(hip_ops.DTPROJ_FUSED and (R + 2 * 16) % 8 == 0 and _lib.load().dm_dtproj_softplus_supported(int(Din), int(R), code))
+
+
+def spiral_ssm_pair(xz0, xz1, mix0, mix1, A0, A1):
+    """The fused 3-direction operator (spiral_ssm) for the two mixers of a block in one set of launches."""
+    with torch.autocast(device_type="cuda", enabled=False):
+        return _SpiralSSMPairFn.apply(xz0, xz1, mix0.scan_index, mix1.scan_index, torch.is_grad_enabled(),
+                                      mix0.conv1d.weight, mix1.conv1d.weight, mix0.conv1d.bias, mix1.conv1d.bias,
+                                      mix0.x_proj.weight, mix1.x_proj.weight, mix0.dt_proj.weight, mix1.dt_proj.weight,
+                                      mix0.dt_proj.bias.float(), mix1.dt_proj.bias.float(), A0.float(), A1.float(),
+                                      mix0.D.float(), mix1.D.float())
 
 
 # ------------------------------------------------------------------------------------------------

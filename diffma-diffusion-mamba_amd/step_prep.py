@@ -78,6 +78,18 @@ def cast_weight(weight, dtype):
     return s if s is not None else weight.to(dtype)
 
 
+def stacked_pair(w0, w1, dtype):
+    """[2, ...] tensor of the two weights in `dtype`: the shared buffer of their shadows when both are current (no launch),
+    else a stack of the casts."""
+    s0, s1 = shadow_of(w0, dtype) if w0.dtype != dtype else None, shadow_of(w1, dtype) if w1.dtype != dtype else None
+    if s0 is not None and s1 is not None:
+        base = s0._base
+        if (base is not None and base is s1._base and base.dim() == s0.dim() + 1 and base.shape[0] == 2
+                and s0.data_ptr() == base.data_ptr() and s1.data_ptr() == base.data_ptr() + s0.numel() * s0.element_size()):
+            return base
+    return torch.stack([cast_weight(w0, dtype), cast_weight(w1, dtype)])
+
+
 def prepare(model, dtype=None):
     """Called at the top of DiffMa.forward when gradients are on and the model is on a ROCm device.  dtype: the 16-bit dtype of the
     weight copies (default: the active CUDA autocast dtype; tests pass it explicitly)."""
@@ -97,7 +109,20 @@ def prepare(model, dtype=None):
             net = getattr(m, "attention_network", None)
             if net is not None:
                 masters += [net[1].weight, net[3].weight]
-        plan = _PLANS[model] = dict(mixers=mixers, masters=masters, shadows={})
+                ada = getattr(m, "adaLN_modulation", None)          # the block's adaLN Linear goes through linear_splitk too (mamba_block.py)
+                if isinstance(ada, torch.nn.Sequential) and isinstance(ada[1], torch.nn.Linear) and ada[1].bias is not None:
+                    masters += [ada[1].weight, ada[1].bias]
+        # weights of two consecutive mixers with equal shapes (mamba1 / mamba2 of a Spiral_MambaBlock): their 16-bit copies are
+        # the two halves of ONE [2, ...] buffer, which the paired-mixer path hands to a batched GEMM as it is (stacked_pair)
+        names = ("in_proj", "out_proj", "x_proj", "dt_proj")
+        mods = [m for m in model.modules() if hasattr(m, "A_log") and all(isinstance(getattr(m, n, None), torch.nn.Linear) for n in names)]
+        partner = {}
+        for a, b in zip(mods[0::2], mods[1::2]):
+            for n in names:
+                wa, wb = getattr(a, n).weight, getattr(b, n).weight
+                if wa.shape == wb.shape and wa.dtype == wb.dtype:
+                    partner[id(wa)] = wb
+        plan = _PLANS[model] = dict(mixers=mixers, masters=masters, shadows={}, partner=partner)
     mixers = plan["mixers"]
     if mixers:
         As = _NegExpAll.apply(*[m.A_log for m in mixers])
@@ -117,9 +142,25 @@ def prepare(model, dtype=None):
                 return
             # Masters were written (an optimizer step).  If an autograd graph still holds the old copies (retain_graph, a backward
             # that has not run yet) they must not be overwritten: new buffers, the old ones die with that graph.
-            fresh = any(s._use_count() > 1 for s in sh)
+            fresh = any(s._use_count() > 1 for s in sh) or any(b._use_count() > n for b, n in plan.get("bases", {}).get(dt, ()))
         if fresh:
-            sh = plan["shadows"][dt] = [torch.empty_like(w, dtype=dt) for w in masters]
+            sh, made, bases = [], {}, []
+            for w in masters:
+                if id(w) in made:
+                    sh.append(made.pop(id(w)))
+                    continue
+                wb = plan["partner"].get(id(w))
+                if wb is not None:
+                    base = torch.empty((2,) + tuple(w.shape), dtype=dt, device=w.device)
+                    sh.append(base[0])
+                    made[id(wb)] = base[1]
+                    bases.append(base)
+                else:
+                    sh.append(torch.empty_like(w, dtype=dt))
+            plan["shadows"][dt] = sh
+            # (a [2, ...] base handed out by stacked_pair may be what an autograd node saved: its reference count at rest
+            #  -- the plan's own reference and its two views -- is the baseline the live-graph check compares with)
+            plan.setdefault("bases", {})[dt] = [(b, b._use_count()) for b in bases]
         with torch.no_grad():
             torch._foreach_copy_(sh, [w.detach() for w in masters])
         for w, s in zip(masters, sh):

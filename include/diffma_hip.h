@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 24
+#define DM_ABI_VERSION 25
 
 typedef enum {
     DM_OK = 0,
@@ -593,6 +593,28 @@ typedef struct {
 } dm_diffusion_step_args;
 
 int dm_diffusion_step(const dm_diffusion_step_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Several congruent launches in one (ABI 25).
+ *
+ * A DiffMa block runs TWO mixers on tensors of the same shape with different weights (reference block/mamba_block.py:107-108),
+ * and the reference's own configuration trains at one sample per GPU (config/brain.yaml:11), where a step is bound by the
+ * NUMBER of kernel launches.  Each function below takes an ARRAY of `n` argument structs and is equivalent to calling its
+ * single-launch namesake on args[0], args[1], ... in order.  Neighbouring structs that are congruent -- every size, stride,
+ * dtype and flag equal, the same pointers NULL -- share ONE launch when the kernel their shape selects is built for it (all of
+ * them except the large-launch sequential scans; the kernel picks its struct by blockIdx.z); anything else is launched one
+ * after the other.  The results are bit-identical to the separate calls.  The launches must be independent of each other.
+ * ---------------------------------------------------------------------------------------------- */
+int dm_selective_scan_fwd_n(const dm_scan_fwd_args *args, int n, void *stream);
+int dm_selective_scan_bwd_n(const dm_scan_bwd_args *args, int n, void *stream);
+int dm_gather_conv1d_fwd_n(const dm_conv_fwd_args *args, int n, void *stream);
+int dm_gather_conv1d_bwd_n(const dm_conv_bwd_args *args, int n, void *stream);
+int dm_token_merge_n(const dm_merge_args *args, int n, void *stream);
+int dm_gate_bwd_n(const dm_gate_bwd_args *args, int n, void *stream);
+int dm_dtproj_softplus_fwd_n(const dm_dtproj_args *args, int n, void *stream);
+int dm_dtproj_bwd_n(const dm_dtproj_bwd_args *args, int n, void *stream);
+int dm_colsum_f32_n(const dm_colsum_args *args, int n, void *stream);
+int dm_sum_partials_n(const dm_sum_partials_args *args, int n, void *stream);
 
 /* Library introspection. */
 int dm_abi_version(void);

@@ -1102,3 +1102,135 @@ def test_dtproj_bwd_unsupported_shapes_fall_back(gpu):
                                             mk(64, 64, dt=torch.float32))
     with pytest.raises(Exception):
         hip_ops.dtproj_bwd(mk(64, 1536), mk(64, 64), mk(1536, 32), mk(64, 64))
+
+
+# ---- several congruent launches in one (dm_*_n entry points, ABI 25): the two mixers of a block ------------------------------
+def test_paired_launches_are_bit_identical_to_separate_ones(gpu):
+    """hip_ops.paired() queues the launches of two independent, congruent calls and issues each pair as ONE `_n` launch (blockIdx.z
+    picks the argument struct).  Every kernel of the small-launch mixer path -- gather + conv forward / backward, dt_proj + softplus
+    and its backward, the chunk-parallel scans, gated merge, gate backward, partial-row sums -- must produce exactly the bits of
+    two separate launches, and the pair must really share launches (counted at the library call)."""
+    from diffma_amd import _lib, hip_ops
+
+    dt = torch.bfloat16
+    Bsz, ndir, L, Din, R, N = 2, 3, 196, 512, 16, 16
+    S, M = ndir * Bsz, ndir * Bsz * L
+    g = torch.Generator(device=gpu).manual_seed(77)
+    mk = lambda *s, sc=1.0: torch.randn(*s, device=gpu, generator=g) * sc
+
+    def mixer_inputs():
+        idx = torch.stack([torch.arange(L, device=gpu)] + [torch.randperm(L, device=gpu, generator=g) for _ in range(ndir - 1)]).to(torch.int32)
+        return dict(xz=mk(Bsz, L, 2 * Din).to(dt), cw=mk(Din, 4, sc=0.4), cb=mk(Din, sc=0.1), Wx=mk(R + 2 * N, Din, sc=Din ** -0.5).to(dt),
+                    Wdt=mk(Din, R, sc=0.3).to(dt), bias=mk(Din, sc=0.5), A=-(torch.rand(Din, N, device=gpu, generator=g) * 4 + 0.2), D=mk(Din),
+                    idx=idx, dy=mk(Bsz, L, Din).to(dt))
+
+    mix = [mixer_inputs(), mixer_inputs()]
+
+    def run(paired):
+        counts = {}
+        real_call, real_call_n = _lib.call, _lib.call_n
+
+        def call(name, a, st):
+            counts[name] = counts.get(name, 0) + 1
+            return real_call(name, a, st)
+
+        def call_n(name, arr, st):
+            counts[name] = counts.get(name, 0) + 1
+            return real_call_n(name, arr, st)
+
+        _lib.call, _lib.call_n = call, call_n
+        try:
+            out = [dict(), dict()]
+
+            def stage(fn):
+                with hip_ops.paired(enabled=paired) as pr:
+                    for k in (0, 1):
+                        if k and paired:
+                            pr.second()
+                        fn(mix[k], out[k])
+
+            def conv(m, o):
+                o["xc"] = hip_ops.gather_conv1d_fwd(m["xz"][..., :Din], m["cw"], m["cb"], row_index=m["idx"], ndir=ndir, silu=True)
+            stage(conv)
+            for k in (0, 1):
+                out[k]["x_dbl"] = (out[k]["xc"].view(M, Din) @ mix[k]["Wx"].t()).contiguous()
+
+            def dtp(m, o):
+                o["delta"] = hip_ops.dtproj_softplus_fwd(o["x_dbl"], m["Wdt"], m["bias"]).view(S, L, Din)
+            stage(dtp)
+
+            def scan(m, o):
+                xd3 = o["x_dbl"].view(S, L, R + 2 * N)
+                o["ckpt"] = hip_ops.alloc_scan_ckpt(S, L, N, Din, dt, gpu)
+                o["ydir"] = hip_ops.scan_fwd(o["xc"], o["delta"], m["A"], xd3[..., R:R + N], xd3[..., R + N:], m["D"], None, m["bias"], True,
+                                             z_row_index=m["idx"], out_row_index=m["idx"], batch_per_dir=Bsz, ckpt=o["ckpt"], delta_activated=True)
+            stage(scan)
+
+            def merge(m, o):
+                o["pre"] = torch.empty((Bsz, L, Din), dtype=dt, device=gpu)
+                o["y"] = hip_ops.token_merge(o["ydir"].view(ndir, Bsz, L, Din), gate=m["xz"][..., Din:], pre_out=o["pre"])
+            stage(merge)
+
+            def gate(m, o):
+                o["dxz"] = torch.zeros((Bsz, L, 2 * Din), dtype=dt, device=gpu)
+                o["g"], _ = hip_ops.gate_bwd(m["dy"], m["xz"][..., Din:], o["pre"], dz_out=o["dxz"][..., Din:])
+            stage(gate)
+
+            def bwd(m, o):
+                xd3 = o["x_dbl"].view(S, L, R + 2 * N)
+                o["dx_dbl"] = torch.zeros((M, R + 2 * N), dtype=dt, device=gpu)
+                o["sb"] = hip_ops.scan_bwd(o["xc"], o["delta"], m["A"], xd3[..., R:R + N], xd3[..., R + N:], m["D"], None, m["bias"], o["g"], o["ckpt"],
+                                           True, z_row_index=m["idx"], out_row_index=m["idx"], batch_per_dir=Bsz,
+                                           dbc_out=o["dx_dbl"].view(S, L, R + 2 * N)[..., R:], delta_activated=True)
+            stage(bwd)
+
+            def dtb(m, o):
+                o["dWdt"] = hip_ops.dtproj_bwd(o["sb"][1].view(M, Din), o["x_dbl"], m["Wdt"], o["dx_dbl"])
+            assert hip_ops.dtproj_bwd_supported(out[0]["sb"][1].view(M, Din), out[0]["x_dbl"], mix[0]["Wdt"], out[0]["dx_dbl"])
+            stage(dtb)
+
+            def cbwd(m, o):
+                o["cb"] = hip_ops.gather_conv1d_bwd(m["xz"][..., :Din], m["cw"], m["cb"], o["sb"][0], row_index=m["idx"], ndir=ndir, silu=True)
+            stage(cbwd)
+
+            def dxm(m, o):
+                hip_ops.token_merge(o["cb"][0].view(ndir, Bsz, L, Din), out=o["dxz"][..., :Din])
+            stage(dxm)
+            torch.cuda.synchronize()
+            return out, counts
+        finally:
+            _lib.call, _lib.call_n = real_call, real_call_n
+
+    ref, c_ref = run(False)
+    got, c_got = run(True)
+
+    def flat(o):
+        res = dict(xc=o["xc"], delta=o["delta"], ydir=o["ydir"], y=o["y"], pre=o["pre"], g=o["g"], dxz=o["dxz"], dx_dbl=o["dx_dbl"], dWdt=o["dWdt"],
+                   ckpt=o["ckpt"], dconv_w=o["cb"][1], dconv_b=o["cb"][2])
+        for i, name in enumerate(("du", "ddelta", "dz", "dB", "dC", "dA", "dD", "dbias")):
+            if o["sb"][i] is not None:
+                res[name] = o["sb"][i]
+        return res
+
+    for k in (0, 1):
+        a, b = flat(ref[k]), flat(got[k])
+        for name in a:
+            assert torch.equal(a[name], b[name]), (k, name)
+    # the forward is really the small-launch family and every kernel of the pair shared its launch
+    assert sum(c_got.values()) * 2 == sum(c_ref.values()), (c_got, c_ref)
+    assert all(c_got[n] * 2 == c_ref[n] for n in c_ref), (c_got, c_ref)
+
+
+def test_n_entry_points_run_incongruent_launches_one_by_one(gpu):
+    """dm_*_n with structs that differ in a size: not one grid, but still both results (the second launch follows the first)."""
+    from diffma_amd import hip_ops
+
+    x0 = torch.randn(3, 40, 256, device=gpu)
+    x1 = torch.randn(5, 40, 256, device=gpu)
+    with hip_ops.paired() as pr:
+        a = hip_ops.colsum(x0.view(-1, 256))
+        pr.second()
+        b = hip_ops.colsum(x1.view(-1, 256))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(a, x0.view(-1, 256).sum(0), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(b, x1.view(-1, 256).sum(0), rtol=1e-5, atol=1e-4)

@@ -1053,7 +1053,7 @@ def test_full_width_mixer_takes_the_fused_dtproj_backward(gpu, monkeypatch):
     n, B, d_model = 4, 8, 512                                       # 3 directions x 8 x 16 tokens = 384 rows
     orders, inverses = spiral(n)
     lists = (orders[2], orders[3], inverses[2], inverses[3])
-    mix = Mamba(d_model=d_model, d_state=d_state, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
+    mix = Mamba(d_model=d_model, d_state=16, token_list=lists[0], token_list_reversal=lists[1], origina_list=lists[2],
                 origina_list_reversal=lists[3]).to(gpu)
     x0 = torch.randn(B, n * n, d_model, device=gpu)
     dy = torch.randn(B, n * n, d_model, device=gpu)
@@ -1101,3 +1101,55 @@ def test_small_batch_weight_gradient_gemm_writes_fp32(gpu):
     assert got.dtype == torch.float32 and got.shape == (96, 512)
     e_new, e_old = rel_l2(got.cpu(), ref.cpu()), rel_l2(rounded.cpu(), ref.cpu())
     assert e_new <= 2e-3 and e_new <= e_old * 1.05, (e_new, e_old)
+
+
+# ---- the two mixers of a block in one set of launches (reference block/mamba_block.py:107-108; config/brain.yaml: 1 sample / GPU) ----
+def test_paired_mixers_equal_two_unpaired_mixers_and_halve_the_launches(gpu, monkeypatch):
+    """Spiral_MambaBlock at the reference's own batch (small launches, bf16 autocast): with the pair path the block's two mixers issue
+    every stage once (kernels: one grid through the `_n` entry points; projections: batched GEMMs) -- the output and every
+    gradient must equal the two-unpaired-mixers form to GEMM rounding, and the mixers' C-ABI launches must halve."""
+    import copy
+
+    from diffma_amd import _lib
+    from diffma_amd import selective_scan_interface as ssi
+    from diffma_amd.mamba_block import Spiral_MambaBlock
+    from diffma_amd.tools import spiral
+
+    torch.manual_seed(4)
+    n, B, C = 14, 2, 512
+    orders, inverses = spiral(n)
+    blk0 = Spiral_MambaBlock(C, C, 32, 2 * C, 16, orders[2], orders[3], inverses[2], inverses[3]).to(gpu)
+    with torch.no_grad():
+        for name, p in blk0.named_parameters():
+            if float(p.abs().max()) == 0.0:
+                p.copy_(torch.randn_like(p) * 0.02)
+    x = torch.randn(B, n * n, C, device=gpu)
+    c = torch.randn(B, 2 * C, device=gpu)
+    w = torch.sigmoid(torch.randn(B, n * n, 1, device=gpu))
+    dy = torch.randn(B, n * n, C, device=gpu)
+
+    def run(pair):
+        monkeypatch.setattr(ssi, "PAIR_MIXERS", pair)
+        blk = copy.deepcopy(blk0)
+        xin = x.clone().requires_grad_(True)
+        counts = {"n": 0}
+        real_call, real_call_n = _lib.call, _lib.call_n
+        monkeypatch.setattr(_lib, "call", lambda name, a, st: (counts.__setitem__("n", counts["n"] + 1), real_call(name, a, st))[1])
+        monkeypatch.setattr(_lib, "call_n", lambda name, a, st: (counts.__setitem__("n", counts["n"] + 1), real_call_n(name, a, st))[1])
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = blk(xin, c, w)
+        (y.float() * dy).sum().backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(_lib, "call", real_call)
+        monkeypatch.setattr(_lib, "call_n", real_call_n)
+        grads = {k: p.grad.detach().float().clone() for k, p in blk.named_parameters() if p.grad is not None}
+        return y.detach().float(), xin.grad.detach().float(), grads, counts["n"]
+
+    y0, dx0, g0, n0 = run(False)
+    y1, dx1, g1, n1 = run(True)
+    assert rel_l2(y1, y0) <= 1e-2 and rel_l2(dx1, dx0) <= 2e-2, (rel_l2(y1, y0), rel_l2(dx1, dx0))
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        assert rel_l2(g1[k], g0[k]) <= 3e-2, (k, rel_l2(g1[k], g0[k]))
+    # block-level kernels (LayerNorms, gate head, blend) are unchanged; the mixers' share of the C-ABI launches halves
+    assert n1 < n0 and (n0 - n1) >= 10, (n0, n1)
