@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--torch-profile", default="", help="developer aid: write a torch.profiler op table of one extra step to this file")
     ap.add_argument("--use-mamba2", action="store_true", help="Mamba-2 (SSD) mixers, BASELINE config 4")
     ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
+    ap.add_argument("--route-a", action="store_true", help="the mixers call mamba_inner_fn three times per mixer exactly as the reference's Mamba.forward does (INTEGRATION.md route A) instead of the fused 3-direction operator: what the plain import swap delivers")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (sample mode: the denoiser call; train mode: the whole optimisation step, with several ranks as two graphs around one gradient all-reduce -- for small batches where the eager step is host-bound)")
     return ap.parse_args()
 
@@ -294,6 +295,110 @@ def gemm_accounting(step, steps_time_ms):
             "source": "one step under FlopCounterMode (FLOPs) and one under torch.profiler (GEMM kernel time), both after the timed region"}
 
 
+def install_route_a():
+    """--route-a: the mixers call the operator the way the REFERENCE's Mamba.forward does after the three-line import swap of
+    INTEGRATION.md section A (reference block/mamba.py:333-355): channel-major xz (B, 2*Din, L) from in_proj, CrossScan as two
+    gathers along L, THREE mamba_inner_fn calls (one per direction, each with its own conv / x_proj / dt_proj / scan / out_proj),
+    CrossMerge as row gathers of the three projected outputs.  What a reference user gets from the drop-in before touching
+    anything else; the native path (one fused 3-direction operator, token-major, merge before out_proj) is `Mamba.forward`."""
+    from diffma_amd import selective_scan_interface as ssi
+    from diffma_amd.mamba import Mamba
+    from diffma_amd.selective_scan_interface import mamba_inner_fn
+
+    ssi.PAIR_MIXERS = False            # the paired path is part of the native mixer, not of the reference's call pattern
+
+    def forward(self, hidden_states, scan_type="spiral", inference_params=None):
+        assert scan_type == "spiral" and inference_params is None
+        Bsz, L, _ = hidden_states.shape
+        idx = getattr(self, "_route_a_idx", None)
+        if idx is None or idx[0].device != hidden_states.device:
+            mk = lambda l: torch.tensor(list(l), dtype=torch.long, device=hidden_states.device)
+            idx = self._route_a_idx = (mk(self.token_list), mk(self.token_list_reversal), mk(self.origina_list), mk(self.origina_list_reversal))
+        order, order_rev, orig, orig_rev = idx
+        xz = (self.in_proj.weight @ hidden_states.reshape(Bsz * L, -1).t()).reshape(-1, Bsz, L).permute(1, 0, 2)     # (B, 2*Din, L), L contiguous
+        A = -torch.exp(self.A_log.float())
+        outs = []
+        for sel in (None, order, order_rev):
+            xk = xz if sel is None else xz[:, :, sel].contiguous()
+            outs.append(mamba_inner_fn(xk, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, self.out_proj.weight,
+                                       self.out_proj.bias, A, None, None, self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True))
+        return outs[0] + outs[1][:, orig, :] + outs[2][:, orig_rev, :]
+
+    Mamba.forward = forward
+
+
+def comm_accounting(step, model, ddp_net, graph_train, rank, world, grad_compression):
+    """What the first real multi-GPU run needs to be read: the gradient bytes all-reduced per step, the number
+    of collectives they travel in, and -- from ONE profiled step after the timed region, rank 0's own trace -- the device time of
+    the RCCL kernels and how much of it was EXPOSED, i.e. not covered by any compute kernel running at the same time.
+    Every rank runs the extra step (it contains the collective); only rank 0 profiles."""
+    import torch.distributed as dist
+    from torch.profiler import ProfilerActivity, profile
+
+    nparam = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    es = 2 if (grad_compression in ("bf16", "fp16") and not graph_train) else 4
+    info = {"gradient_elements": nparam, "bytes_all_reduced_per_step": nparam * es,
+            "wire_dtype": {2: grad_compression, 4: "fp32"}[es], "world": world,
+            # ring all-reduce = reduce-scatter + all-gather: every rank sends and receives 2 (N - 1) / N of the payload
+            "bytes_on_the_wire_per_rank": int(2 * (world - 1) / max(world, 1) * nparam * es)}
+    if graph_train:
+        info["collectives_per_step"] = 1
+        info["schedule"] = "graph 1 (forward + backward + flatten) | ONE all_reduce(AVG) of the flat fp32 gradient | graph 2 (AdamW + EMA): not overlapped"
+    else:
+        nb = None
+        try:
+            ld = ddp_net._get_ddp_logging_data()
+            nb = ld.get("num_buckets") or (len(str(ld.get("bucket_sizes", "")).split(",")) if ld.get("bucket_sizes") else None)
+            info["bucket_cap_MB"] = ld.get("bucket_cap_bytes", 0) / 2 ** 20 if ld.get("bucket_cap_bytes") else None
+        except Exception:
+            pass
+        info["collectives_per_step"] = int(nb) if nb else None
+        info["schedule"] = "DistributedDataParallel buckets (gradient_as_bucket_view, static_graph), all-reduced on RCCL's stream while the backward continues"
+    torch.cuda.synchronize()
+    dist.barrier()
+    if rank == 0:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+    else:
+        step()
+        torch.cuda.synchronize()
+    dist.barrier()
+    if rank != 0:
+        return None
+    comm, comp = [], []
+    for e in prof.events():
+        if e.device_type != torch.autograd.DeviceType.CUDA:
+            continue
+        iv = (e.time_range.start, e.time_range.end)
+        name = e.name.lower()
+        (comm if ("nccl" in name or "rccl" in name) else comp).append(iv)
+    from diffma_amd.hip_ops import union_length
+    busy = union_length(comm)
+    # exposed = the part of the collectives' busy time during which no compute kernel was running
+    covered = 0.0
+    comp_sorted = sorted(comp)
+    for s0, e0 in _merge(comm):
+        covered += union_length((max(s0, a), min(e0, b)) for a, b in comp_sorted if b > s0 and a < e0)
+    span = (max(e for _, e in comm + comp) - min(s for s, _ in comm + comp)) if (comm or comp) else 0.0
+    info.update({"rccl_kernel_launches": len(comm), "rccl_kernel_ms": round(sum(e - s for s, e in comm) / 1e3, 3),
+                 "rccl_busy_ms": round(busy / 1e3, 3), "rccl_exposed_ms": round((busy - covered) / 1e3, 3),
+                 "profiled_step_ms": round(span / 1e3, 3),
+                 "note": "one profiled step after the timed region (rank 0's trace): rccl_busy = union of the RCCL kernels' intervals, "
+                         "exposed = the part of it with no compute kernel running; on one GPU (BENCH_FORCE_DDP=1) the collective is a local copy"})
+    return info
+
+
+def _merge(intervals):
+    out = []
+    for s0, e0 in sorted(intervals):
+        if out and s0 <= out[-1][1]:
+            out[-1][1] = max(out[-1][1], e0)
+        else:
+            out.append([s0, e0])
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,6 +427,8 @@ def main():
             os.makedirs(os.path.join(os.getcwd(), "gpurun_out"), exist_ok=True)
             wf = os.path.join(os.getcwd(), "gpurun_out", f"gemm_tuning_rank{rank}.csv")
         gemm_tuning.enable_tuned_gemms(tune_missing=args.gemm_tuning != "frozen", write_file=wf)
+    if args.route_a:
+        install_route_a()
     torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
     model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=args.use_mamba2)
     rerandomize_zero_init(model, 1)
@@ -419,6 +526,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     assert torch.isfinite(last.detach().float()).all(), "non-finite loss/sample in the timed region"
+    comm = None
+    if (world > 1 or force_ddp) and args.mode == "train":
+        comm = comm_accounting(step, model, net, args.graph, rank, world, os.environ.get("DIFFMA_GRAD_COMPRESSION", "none"))
 
     if rank == 0:
         ksum = timer.summary()
@@ -485,7 +595,8 @@ def main():
             "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1 and not force_ddp) else (", step replayed from two hipGraphs around one gradient all-reduce" if args.graph else "")) if args.mode == "train"
                        else f"{args.model} {'p_sample step (250-step respaced DDPM)' if args.sampler == 'ddpm250' else 'ddim_sample step (50-step DDIM)'}, batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
-                       "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning},
+                       "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning,
+                       **({"route": "A: three mamba_inner_fn calls per mixer, reference call pattern (block/mamba.py:346-348)"} if args.route_a else {})},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "frac_design": round(design_per_launch / HBM_PEAK_GBPS, 4),
@@ -512,6 +623,8 @@ def main():
         }
         _log(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms/step")
         res["config"]["world_size_seen_by_rccl"] = dist.get_world_size() if dist.is_initialized() else 1
+        if comm is not None:
+            res["comm"] = comm
         if not args.no_extras:
             if args.mode == "train" and world == 1 and not args.graph:      # extra steps on one rank only: never with peers waiting in an all-reduce
                 res["gemm"] = gemm_accounting(step, 1e3 * elapsed / args.steps)

@@ -382,18 +382,18 @@ class _SpiralSSMFn(torch.autograd.Function):
 # library rounding.  Used for small launches only (below the fused conv + x_proj threshold); large batches gain nothing from it.
 PAIR_MIXERS = os.environ.get("DIFFMA_PAIR_MIXERS", "1") == "1"
 
-# How the pair path multiplies by the two mixers' projection weights.  "bmm": ONE batched GEMM per product -- issued with TunableOp's
-# first-use tuning switched off around the call: tuning these batch-2 shapes runs library candidates that fault (MI355X, ROCm 7.2:
-# memory access faults inside the tuning loop at [2, 4704, 1024] x [2, 1024, 64] and, at one sample per GPU, at the in_proj /
-# out_proj shapes -- tools/dbg_bmm.py); the library's default choice is safe, but for an unrecorded batched shape it costs host time
-# on every call, which an eager small-batch step is made of.  "mm": one plain GEMM per mixer (the products the unpaired path has
-# always issued, tuned and recorded).  "auto" (default): bmm inside a hipGraph capture, where host time is paid once, mm otherwise.
-PAIR_GEMM = os.environ.get("DIFFMA_PAIR_GEMM", "bmm")
+# How the pair path multiplies by the two mixers' projection weights.  "mm" (default): one plain GEMM per mixer -- the products the
+# unpaired path has always issued, tuned and recorded.  "bmm": ONE batched GEMM per product (batch = 2), with TunableOp's first-use
+# tuning switched off around the call.  Measured gain of bmm at DiffMa-L/2: graphed step 16.5 -> 15.4 ms at batch 8, 11.3 -> 10.3 ms
+# at one sample.  It is NOT the default because the vendor library cannot be trusted with these shapes (MI355X, ROCm 7.2,
+# tools/dbg_bmm.py, each case in its own process): torch.bmm([2, 12544, 1024] x [2, 1024, 512]) -- out_proj at batch 64 -- returns
+# NaN / faults with the library's DEFAULT kernel, while M = 196, 1568, 3136 and 33320 of the same product are correct; under
+# TunableOp's tuning loop [2, 4704, 1024] x [2, 1024, 64] and the one-sample in_proj / out_proj shapes fault as well.  A wrong
+# kernel at some batch size in between is not something a training run can be exposed to; own batched GEMMs would lift this.
+PAIR_GEMM = os.environ.get("DIFFMA_PAIR_GEMM", "mm")
 
 
 def _pair_use_bmm(t):
-    if PAIR_GEMM == "auto":
-        return t.is_cuda and torch.cuda.is_current_stream_capturing()
     return PAIR_GEMM == "bmm"
 
 
@@ -891,7 +891,7 @@ def mamba_split_conv1d_scan_combined(zxbcdt, conv1d_weight, conv1d_bias, dt_bias
     # ONE autograd node, the same one the Mamba2 module runs with three directions: conv (K3), the single-chunk SSD core on the
     # matrix pipe (dm_ssd_fwd / dm_ssd_bwd) when the shape allows it -- 16-bit I/O, headdim 64, d_state 16, 16-byte aligned rows --
     # else the A-shared selective scan, then the gated RMSNorm (dm_rmsnorm_merge_*, one slab) when rmsnorm_weight is given.
-    ident = torch.arange(L, device=zxbcdt.device, dtype=torch.int32)[None]
+    ident = _const("ident", L, zxbcdt.device)
     y = spiral_ssd(zxbcdt, conv1d_weight, conv1d_bias, dt_bias, A, D, rmsnorm_weight, rmsnorm_eps, ident, ident, dim, N)
     if outproj_weight is not None:
         y = F.linear(y, outproj_weight.to(y.dtype), outproj_bias)
@@ -910,6 +910,20 @@ def spiral_ssm(xz, conv_w, conv_b, x_proj_w, dt_proj_w, dt_proj_b, A, Dskip, sca
                                   scan_index, torch.is_grad_enabled(), out_index, merge)
 
 
+_CONSTS = {}
+
+
+def _const(kind, n, device):
+    """Identity row table / zero vector of the reference-facing operators, cached per (kind, size, device): the per-call
+    torch.arange / torch.zeros were two launches of every mamba_inner_fn call (three calls per mixer on route A)."""
+    key = (kind, int(n), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = torch.arange(n, device=device, dtype=torch.int32)[None] if kind == "ident" else torch.zeros(n, device=device)
+        _CONSTS[key] = t
+    return t
+
+
 def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, out_proj_weight,
                    out_proj_bias, A, B=None, C=None, D=None, delta_bias=None, B_proj_bias=None,
                    C_proj_bias=None, delta_softplus=True):
@@ -922,8 +936,8 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     if not delta_softplus:
         raise NotImplementedError("mamba_inner_fn is only defined with delta_softplus=True upstream")
     xzt = _to_token_major(xz)                                                    # [B, L, 2Din]
-    ident = torch.arange(xzt.shape[1], device=xz.device, dtype=torch.int32)[None]
-    bias = delta_bias if delta_bias is not None else torch.zeros(xzt.shape[2] // 2, device=xz.device)
-    Dsk = D if D is not None else torch.zeros(xzt.shape[2] // 2, device=xz.device)
+    ident = _const("ident", xzt.shape[1], xz.device)                              # made once per (length, device), not per call
+    bias = delta_bias if delta_bias is not None else _const("zeros", xzt.shape[2] // 2, xz.device)
+    Dsk = D if D is not None else _const("zeros", xzt.shape[2] // 2, xz.device)
     y = spiral_ssm(xzt, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, bias, A, Dsk, ident)
     return F.linear(y, out_proj_weight.to(y.dtype), out_proj_bias)
