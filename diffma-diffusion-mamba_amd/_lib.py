@@ -99,6 +99,7 @@ dm_sum_partials_args = _make_struct("dm_sum_partials_args")
 dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
 dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
 dm_ssd_bwd_args = _make_struct("dm_ssd_bwd_args")
+dm_gemm_args = _make_struct("dm_gemm_args")
 
 _lib = None
 _lock = threading.Lock()
@@ -139,6 +140,8 @@ def load():
                 fn.argtypes = [ctypes.c_int] * 5
             elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported", "dm_dtproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+            elif name == "dm_gemm_supported":
+                fn.argtypes = [ctypes.c_int] * 7
             elif name.endswith("_n"):                    # an array of n argument structs (several congruent launches in one)
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
             else:

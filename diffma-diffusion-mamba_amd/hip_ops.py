@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -731,6 +731,47 @@ def dtproj_bwd(ddelta, xdbl, w, dxdbl):
     es = ddelta.element_size()
     _launch("dm_dtproj_bwd", a, ddelta, M * (Dm + 2 * R) * es + Dm * R * (es + 4))
     return colsum(part).view(Dm, R)
+
+
+# ------------------------------------------------------------------------------------------------
+# Dense products of the projections in the small-launch regime (csrc/gemm.hip)
+# ------------------------------------------------------------------------------------------------
+def _gemm_dims(a, b, a_kmajor, b_kmajor):
+    P, Kc = (a.shape[0], a.shape[1]) if a_kmajor else (a.shape[1], a.shape[0])
+    Q, Kb = (b.shape[0], b.shape[1]) if b_kmajor else (b.shape[1], b.shape[0])
+    if Kb != Kc:
+        raise ValueError(f"contraction sizes differ: {Kc} vs {Kb}")
+    return P, Q, Kc
+
+
+def gemm_supported(a, b, a_kmajor, b_kmajor, out_dtype=None):
+    """a, b: 2-D stored matrices (column stride 1).  See include/diffma_hip.h dm_gemm_args."""
+    if not (a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and b.dtype == a.dtype and a.dim() == 2 and b.dim() == 2):
+        return False
+    if a.stride(1) != 1 or b.stride(1) != 1 or a.stride(0) % 8 or b.stride(0) % 8 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return False
+    P, Q, Kc = _gemm_dims(a, b, a_kmajor, b_kmajor)
+    cd = _DT[out_dtype or a.dtype]
+    return bool(_lib.load().dm_gemm_supported(P, Q, Kc, int(a_kmajor), int(b_kmajor), dtype_code(a), cd))
+
+
+def gemm(a, b, a_kmajor=True, b_kmajor=True, out=None, out_dtype=None, accumulate=False):
+    """C[P, Q] = opA(a) @ opB(b) on the matrix pipe, fp32 accumulation (csrc/gemm.hip).  a_kmajor: a is [P, Kc], else [Kc, P];
+    b_kmajor: b is [Q, Kc], else [Kc, Q].  forward: gemm(x, W); dgrad: gemm(dy, W, True, False); wgrad: gemm(dy, x, False, False,
+    out_dtype=torch.float32)."""
+    _require_gpu(a, b)
+    P, Q, Kc = _gemm_dims(a, b, a_kmajor, b_kmajor)
+    if out is None:
+        out = torch.empty((P, Q), dtype=out_dtype or a.dtype, device=a.device)
+    g = dm_gemm_args()
+    g.P, g.Q, g.Kc = P, Q, Kc
+    g.ab_dtype, g.c_dtype = dtype_code(a), dtype_code(out)
+    g.a_kmajor, g.b_kmajor = int(a_kmajor), int(b_kmajor)
+    g.accumulate = int(bool(accumulate))
+    g.a, g.b, g.c = _ptr(a), _ptr(b), _ptr(out)
+    g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+    _launch("dm_gemm", g, a, (P * Kc + Q * Kc) * a.element_size() + P * Q * out.element_size())
+    return out
 
 
 LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK

@@ -208,6 +208,14 @@ def _tn_splitk_impl(a, b):
     return _mm_f32(a.t(), b)
 
 
+def _own_single(a, b, a_kmajor, b_kmajor, out_dtype=None):
+    """dm_gemm for ONE product: same row bound as the paired form, and only for matrices with at least 64 rows (below that a GEMM
+    is a handful of workgroups either way)."""
+    rows = a.shape[0]
+    return (PAIR_GEMM == "own" and 64 <= rows <= PAIR_OWN_MAX_ROWS and a.dim() == 2 and b.dim() == 2
+            and hip_ops.gemm_supported(a, b, a_kmajor, b_kmajor, out_dtype))
+
+
 class _LinearSplitKFn(torch.autograd.Function):
     """F.linear whose weight gradient uses the split-K product above (the projections' dW GEMMs have K = B*L)."""
 
@@ -219,6 +227,9 @@ class _LinearSplitKFn(torch.autograd.Function):
         wc = cast_weight(weight, dt_)                    # the step's shadow copy when current (step_prep), else a cast
         ctx.save_for_backward(xc, wc)
         ctx.meta = (x.dtype, weight.dtype, None if bias is None else bias.dtype)
+        if bias is None and xc.is_cuda and _own_single(xc.reshape(-1, xc.shape[-1]), wc, True, True):
+            # small launches: the own kernel is faster than the library's quantised tile grid (csrc/gemm.hip)
+            return hip_ops.gemm(xc.reshape(-1, xc.shape[-1]), wc).view(*xc.shape[:-1], wc.shape[0])
         return GemmChain.run(F.linear, xc, wc, None if bias is None else cast_weight(bias, dt_))
 
     @staticmethod
@@ -230,8 +241,19 @@ class _LinearSplitKFn(torch.autograd.Function):
             if dy2.dtype != xc.dtype:
                 dy2 = dy2.to(xc.dtype)
             x2 = xc.reshape(-1, xc.shape[-1])
-            dx = GemmChain.run(torch.mm, dy2, wc).view(xc.shape).to(x_dt) if ctx.needs_input_grad[0] else None
-            dw = _tn_splitk(dy2.contiguous(), x2.contiguous()).to(w_dt) if ctx.needs_input_grad[1] else None
+            dy2c, x2c = dy2.contiguous(), x2.contiguous()
+            if not ctx.needs_input_grad[0]:
+                dx = None
+            elif b_dt is None and _own_single(dy2c, wc, True, False):
+                dx = hip_ops.gemm(dy2c, wc, True, False).view(xc.shape).to(x_dt)
+            else:
+                dx = GemmChain.run(torch.mm, dy2, wc).view(xc.shape).to(x_dt)
+            if not ctx.needs_input_grad[1]:
+                dw = None
+            elif b_dt is None and _own_single(dy2c, x2c, False, False, torch.float32):
+                dw = hip_ops.gemm(dy2c, x2c, False, False, out_dtype=torch.float32).to(w_dt)
+            else:
+                dw = _tn_splitk(dy2c, x2c).to(w_dt)
             db = dy2.sum(0, dtype=torch.float32).to(b_dt) if (b_dt is not None and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
@@ -382,19 +404,36 @@ class _SpiralSSMFn(torch.autograd.Function):
 # library rounding.  Used for small launches only (below the fused conv + x_proj threshold); large batches gain nothing from it.
 PAIR_MIXERS = os.environ.get("DIFFMA_PAIR_MIXERS", "1") == "1"
 
-# How the pair path multiplies by the two mixers' projection weights.  "mm" (default): one plain GEMM per mixer -- the products the
-# unpaired path has always issued, tuned and recorded.  "bmm": ONE batched GEMM per product (batch = 2), with TunableOp's first-use
-# tuning switched off around the call.  Measured gain of bmm at DiffMa-L/2: graphed step 16.5 -> 15.4 ms at batch 8, 11.3 -> 10.3 ms
-# at one sample.  It is NOT the default because the vendor library cannot be trusted with these shapes (MI355X, ROCm 7.2,
-# tools/dbg_bmm.py, each case in its own process): torch.bmm([2, 12544, 1024] x [2, 1024, 512]) -- out_proj at batch 64 -- returns
-# NaN / faults with the library's DEFAULT kernel, while M = 196, 1568, 3136 and 33320 of the same product are correct; under
-# TunableOp's tuning loop [2, 4704, 1024] x [2, 1024, 64] and the one-sample in_proj / out_proj shapes fault as well.  A wrong
-# kernel at some batch size in between is not something a training run can be exposed to; own batched GEMMs would lift this.
-PAIR_GEMM = os.environ.get("DIFFMA_PAIR_GEMM", "mm")
+# How the pair path multiplies by the two mixers' projection weights.
+#   "own" (default): dm_gemm (csrc/gemm.hip), ONE launch for both mixers through hip_ops.paired() -- up to PAIR_OWN_MAX_ROWS rows per
+#          mixer, where it is also faster on the device than the library's two GEMMs (DiffMa-L/2 widths, both mixers, us incl. launch,
+#          tools/bench_gemm_own.py: batch 8 in_proj 43 -> 21 forward, 42 -> 30 weight gradient, out_proj 41 -> 16 / 38 -> 15 / 40 -> 22;
+#          from ~6 000 rows the library's large tiles win); above that, and for shapes dm_gemm does not take, "mm".
+#   "mm":  one plain library GEMM per mixer -- the products the unpaired path has always issued, tuned and recorded.
+#   "bmm": ONE batched library GEMM per product (batch = 2), TunableOp's first-use tuning switched off around the call.  NOT safe:
+#          torch.bmm([2, 12544, 1024] x [2, 1024, 512]) -- out_proj at batch 64 -- returns NaN / faults with the library's DEFAULT kernel
+#          (MI355X, ROCm 7.2, tools/dbg_bmm.py, each case in its own process), while M = 196, 1568, 3136 and 33320 of the same product
+#          are correct; under the tuning loop [2, 4704, 1024] x [2, 1024, 64] and the one-sample in_proj / out_proj shapes fault too.
+PAIR_GEMM = os.environ.get("DIFFMA_PAIR_GEMM", "own")
+PAIR_OWN_MAX_ROWS = int(os.environ.get("DIFFMA_PAIR_OWN_MAX_ROWS", "3200"))
 
 
 def _pair_use_bmm(t):
     return PAIR_GEMM == "bmm"
+
+
+def _pair_use_own(rows, a, b, a_kmajor, b_kmajor, out_dtype=None):
+    return PAIR_GEMM == "own" and rows <= PAIR_OWN_MAX_ROWS and hip_ops.gemm_supported(a, b, a_kmajor, b_kmajor, out_dtype)
+
+
+def _own_pair(a, b, a_kmajor, b_kmajor, out, accumulate=False):
+    """out[g] (+)= opA(a[g]) @ opB(b[g]) for g = 0, 1 in ONE launch (dm_gemm_n)."""
+    with hip_ops.paired() as pr:
+        for g in (0, 1):
+            if g:
+                pr.second()
+            hip_ops.gemm(a[g], b[g], a_kmajor, b_kmajor, out=out[g], accumulate=accumulate)
+    return out
 
 
 def _bmm_untuned(x, y, out_dtype=None):
@@ -446,7 +485,11 @@ class _LinearPairFn(torch.autograd.Function):
         ctx.save_for_backward(xp, Wst)
         ctx.meta = (x0.dtype, W0.dtype)
         K = xp.shape[-1]
-        y = _pair_matmul(xp.view(2, -1, K), Wst.transpose(1, 2))                                          # [2, M, N]
+        x2 = xp.view(2, -1, K)
+        if _pair_use_own(x2.shape[1], x2[0], Wst[0], True, True):
+            y = _own_pair(x2, Wst, True, True, torch.empty((2, x2.shape[1], Wst.shape[1]), dtype=dt_, device=xp.device))
+        else:
+            y = _pair_matmul(x2, Wst.transpose(1, 2))                                                      # [2, M, N]
         y = y.view(2, *x0.shape[:-1], Wst.shape[1])
         return y[0], y[1]
 
@@ -459,10 +502,16 @@ class _LinearPairFn(torch.autograd.Function):
             dy = _as_pair(dy0.contiguous() if dy0.dtype == xp.dtype else dy0.contiguous().to(xp.dtype),
                           dy1.contiguous() if dy1.dtype == xp.dtype else dy1.contiguous().to(xp.dtype)).view(2, -1, N)
             x2 = xp.view(2, -1, K)
-            dx = _pair_matmul(dy, Wst).view(xp.shape)
+            M = dy.shape[1]
+            if _pair_use_own(M, dy[0], Wst[0], True, False):
+                dx = _own_pair(dy, Wst, True, False, torch.empty((2, M, K), dtype=dy.dtype, device=dy.device)).view(xp.shape)
+            else:
+                dx = _pair_matmul(dy, Wst).view(xp.shape)
             if dx.dtype != x_dt:
                 dx = dx.to(x_dt)
-            if _pair_use_bmm(dy):
+            if _pair_use_own(M, dy[0], x2[0], False, False, torch.float32):
+                dW = _own_pair(dy, x2, False, False, torch.empty((2, N, K), dtype=torch.float32, device=dy.device))
+            elif _pair_use_bmm(dy):
                 dW = _pair_matmul(dy.transpose(1, 2), x2, torch.float32)                                   # [2, N, K] fp32
             else:
                 dW = (_tn_splitk(dy[0], x2[0]), _tn_splitk(dy[1], x2[1]))                                  # the unpaired path's products
@@ -501,8 +550,12 @@ class _SpiralSSMPairFn(torch.autograd.Function):
         # run a library candidate that faults (MI355X, ROCm 7.2: memory access fault inside the tuning loop, tools/dbg_bmm.py);
         # the plain products below are the ones the unpaired path has always issued
         x_dbl = torch.empty((2, M, R + 2 * N), dtype=dt_, device=dev)
-        for g in (0, 1):
-            GemmChain.run(torch.mm, xc[g].view(M, Din), Wx_st[g].t(), out=x_dbl[g])
+        xc2 = xc.view(2, M, Din)
+        if _pair_use_own(M // 4, xc2[0], Wx_st[0], True, True):        # (a 64-column product: the own kernel holds up to ~4x the rows)
+            _own_pair(xc2, Wx_st, True, True, x_dbl)
+        else:
+            for g in (0, 1):
+                GemmChain.run(torch.mm, xc2[g], Wx_st[g].t(), out=x_dbl[g])
         delta = [None, None]
         with hip_ops.paired() as pr:
             for g in (0, 1):
@@ -574,9 +627,17 @@ class _SpiralSSMPairFn(torch.autograd.Function):
             for g in (0, 1):
                 dx_dbl[g][:, :R] = GemmChain.run(torch.mm, ddelta[g], Wdt_st[g])
                 dWdt[g] = _tn_splitk(ddelta[g], x_dbl[g][:, :R])
-        dWx = [_tn_splitk(dx_dbl[g], xc[g].view(M, Din)) for g in (0, 1)]                   # [R+2N, Din] fp32 each (per mixer: see the forward)
-        for g in (0, 1):
-            GemmChain.run(du[g].view(M, Din).addmm_, dx_dbl[g], Wx_st[g])                   # d x~ = du + dx_dbl @ Wx, in place
+        xc2 = xc.view(2, M, Din)
+        if _pair_use_own(M // 4, dx_dbl[0], xc2[0], False, False, torch.float32):
+            dWx = _own_pair(dx_dbl, xc2, False, False, torch.empty((2, R + 2 * N, Din), dtype=torch.float32, device=dev))
+        else:
+            dWx = [_tn_splitk(dx_dbl[g], xc2[g]) for g in (0, 1)]                          # [R+2N, Din] fp32 each
+        du2 = du.view(2, M, Din)
+        if _pair_use_own(M // 4, dx_dbl[0], Wx_st[0], True, False):
+            _own_pair(dx_dbl, Wx_st, True, False, du2, accumulate=True)                    # d x~ = du + dx_dbl @ Wx, in place, one launch
+        else:
+            for g in (0, 1):
+                GemmChain.run(du2[g].addmm_, dx_dbl[g], Wx_st[g])
         dxc = du
         cres = [None, None]
         with hip_ops.paired() as pr:

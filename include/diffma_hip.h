@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 25
+#define DM_ABI_VERSION 26
 
 typedef enum {
     DM_OK = 0,
@@ -595,6 +595,33 @@ typedef struct {
 int dm_diffusion_step(const dm_diffusion_step_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Dense product for the mixer's projections in the small-launch regime (ABI 26):  C[P][Q] = opA(A)[P][Kc] * opB(B)[Kc][Q],
+ * 16-bit operands (bf16 / fp16), fp32 accumulation on the matrix pipe, C in fp32 or in the operand dtype.
+ * Replaces the library GEMMs of  in_proj / out_proj  (reference block/mamba.py:261,315; called at :333-337 and inside
+ * mamba_inner_fn, :346) and of their two gradients where a training step is bound by the number of launches (one sample per GPU,
+ * config/brain.yaml:11) -- dm_gemm_n below multiplies for both mixers of a block in ONE launch.
+ *   a_kmajor = 1: A is stored [P][Kc] (row stride lda);  0: stored [Kc][P]
+ *   b_kmajor = 1: B is stored [Q][Kc] (row stride ldb);  0: stored [Kc][Q]
+ *   forward   y  = x W^T  : A = x  [M][K] (1), B = W [N][K] (1)            -> [M][N]
+ *   dgrad     dx = dy W   : A = dy [M][N] (1), B = W [N][K] (0)            -> [M][K]
+ *   wgrad     dW = dy^T x : A = dy [M][N] (0), B = x [M][K] (0), C fp32    -> [N][K]
+ * Q % 8 == 0; the contiguous index of every operand a multiple of 8; 16-byte aligned tensors; row strides % 8 (C: % 4).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t P, Q, Kc;
+    int32_t ab_dtype;        /* DM_BF16 or DM_F16 */
+    int32_t c_dtype;         /* DM_F32 or ab_dtype */
+    int32_t a_kmajor, b_kmajor;
+    int32_t accumulate;      /* 1: C += product (C is read in c_dtype), 0: C = product */
+    const void *a, *b;
+    void *c;
+    int64_t lda, ldb, ldc;   /* row strides of the STORED matrices, elements */
+} dm_gemm_args;
+
+int dm_gemm(const dm_gemm_args *args, void *stream);
+int dm_gemm_supported(int P, int Q, int Kc, int a_kmajor, int b_kmajor, int ab_dtype, int c_dtype);
+
+/* ------------------------------------------------------------------------------------------------
  * Several congruent launches in one (ABI 25).
  *
  * A DiffMa block runs TWO mixers on tensors of the same shape with different weights (reference block/mamba_block.py:107-108),
@@ -615,6 +642,7 @@ int dm_dtproj_softplus_fwd_n(const dm_dtproj_args *args, int n, void *stream);
 int dm_dtproj_bwd_n(const dm_dtproj_bwd_args *args, int n, void *stream);
 int dm_colsum_f32_n(const dm_colsum_args *args, int n, void *stream);
 int dm_sum_partials_n(const dm_sum_partials_args *args, int n, void *stream);
+int dm_gemm_n(const dm_gemm_args *args, int n, void *stream);
 
 /* Library introspection. */
 int dm_abi_version(void);

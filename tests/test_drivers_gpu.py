@@ -348,7 +348,7 @@ def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["world_size_seen_by_rccl"] == 1 and d["config"]["parallelism"].startswith("dp1")
     assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["roofline"]["frac"] < 1
-    assert d["roofline"]["kernel"].startswith("dm_selective_scan")
+    assert d["roofline"]["kernel"].startswith("dm_")        # (at this test's 4 samples the projections' dm_gemm can outweigh the scans)
     assert ("two hipGraphs" in d["config"]["workload"]) == graph
 
 

@@ -1234,3 +1234,62 @@ def test_n_entry_points_run_incongruent_launches_one_by_one(gpu):
     torch.cuda.synchronize()
     torch.testing.assert_close(a, x0.view(-1, 256).sum(0), rtol=1e-5, atol=1e-4)
     torch.testing.assert_close(b, x1.view(-1, 256).sum(0), rtol=1e-5, atol=1e-4)
+
+
+# ---- dm_gemm: the projections' dense products in the small-launch regime (csrc/gemm.hip) -------------------------------------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [196, 1568, 200, 4704])
+def test_gemm_matches_fp64_matmul(gpu, dtype, M):
+    """The three products of a Linear layer at the mixer's real widths (in_proj 512 -> 2048, out_proj 1024 -> 512, x_proj 1024 -> 64)
+    and a ragged row count, against fp64 matmul of the same 16-bit operands: forward, input gradient, weight gradient (fp32 out),
+    and the accumulating form; rel-L2 <= 1e-2 (bf16) / 2e-3 (fp16) for 16-bit results, 1e-5 for fp32 results."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator(device=gpu).manual_seed(M)
+    mk = lambda *s: (torch.randn(*s, device=gpu, generator=g)).to(dtype)
+    tol16 = 1e-2 if dtype == torch.bfloat16 else 2e-3
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    for K, N in ((512, 2048), (1024, 512), (1024, 64)):
+        x, W, dy = mk(M, K), mk(N, K) * K ** -0.5, mk(M, N)
+        assert hip_ops.gemm_supported(x, W, True, True) and hip_ops.gemm_supported(dy, W, True, False)
+        y = hip_ops.gemm(x, W)                                                   # y = x W^T
+        assert rel(y, x.double() @ W.double().t()) <= tol16
+        dx = hip_ops.gemm(dy, W, True, False)                                    # dx = dy W
+        assert rel(dx, dy.double() @ W.double()) <= tol16
+        dW = hip_ops.gemm(dy, x, False, False, out_dtype=torch.float32)          # dW = dy^T x
+        assert dW.dtype == torch.float32 and rel(dW, dy.double().t() @ x.double()) <= 1e-5
+        acc = mk(M, K)
+        want = acc.double() + dy.double() @ W.double()
+        hip_ops.gemm(dy, W, True, False, out=acc, accumulate=True)               # acc += dy W
+        assert rel(acc, want) <= tol16
+        # strided operands: a column block of a wider buffer (the x half of xz, the dt columns of x_dbl)
+        wide = mk(M, 2 * K)
+        yv = hip_ops.gemm(wide[:, K:], W)
+        assert rel(yv, wide[:, K:].double() @ W.double().t()) <= tol16
+    torch.cuda.synchronize()
+
+
+def test_gemm_pair_is_bit_identical_to_two_launches(gpu):
+    from diffma_amd import _lib, hip_ops
+
+    g = torch.Generator(device=gpu).manual_seed(5)
+    mk = lambda *s: torch.randn(*s, device=gpu, generator=g).bfloat16()
+    x, W, dy = [mk(392, 512), mk(392, 512)], [mk(2048, 512), mk(2048, 512)], [mk(392, 2048), mk(392, 2048)]
+    ref = [(hip_ops.gemm(x[k], W[k]), hip_ops.gemm(dy[k], W[k], True, False), hip_ops.gemm(dy[k], x[k], False, False, out_dtype=torch.float32)) for k in (0, 1)]
+    calls = []
+    real = _lib.call_n
+    _lib.call_n = lambda name, arr, st: (calls.append(name), real(name, arr, st))[1]
+    try:
+        got = [None, None]
+        with hip_ops.paired() as pr:
+            for k in (0, 1):
+                if k:
+                    pr.second()
+                got[k] = (hip_ops.gemm(x[k], W[k]), hip_ops.gemm(dy[k], W[k], True, False), hip_ops.gemm(dy[k], x[k], False, False, out_dtype=torch.float32))
+    finally:
+        _lib.call_n = real
+    torch.cuda.synchronize()
+    assert calls == ["dm_gemm"] * 3
+    for k in (0, 1):
+        for a, b in zip(ref[k], got[k]):
+            assert torch.equal(a, b)
