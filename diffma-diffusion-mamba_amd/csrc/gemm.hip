@@ -17,7 +17,7 @@
 //   row-major : stored [Kc][rows], the OTHER index contiguous        (W in dx = dy W; dy and x in dW = dy^T x)
 // Both end up in LDS as [row][32 k] images (80-byte rows: 16 bytes of padding keep the 16-lane fragment reads off each other's
 // banks); a k-major tile is copied with 16-byte accesses, a row-major tile is loaded with 16-byte accesses along its contiguous
-// index and transposed by its 2-byte LDS stores.  Fragments for v_mfma_f32_16x16x32_{bf16,f16}: lane (i = l & 15, g = l >> 4)
+// index, stored as it is, and transposed by `ds_read_b64_tr_b16` fragment reads.  Fragments for v_mfma_f32_16x16x32_{bf16,f16}: lane (i = l & 15, g = l >> 4)
 // reads the 16 bytes k = 8g .. 8g+7 of row i -- the same mapping for both operands, so the product is issued as B-rows x A-rows
 // (operands swapped): accumulator register r of lane l is then C[m = l & 15][n = 4 (l >> 4) + r], four CONSECUTIVE columns of
 // one output row, and leaves as one 8-byte (16-bit C) or 16-byte (fp32 C) store.
@@ -38,6 +38,17 @@ template <int BK> struct gm_lds {
     static constexpr int LROW = BK + 8;
     static __device__ __forceinline__ int off(int row, int k) { return row * LROW + ((((k >> 3) ^ (row >> 3)) & (BK / 8 - 1)) << 3) + (k & 7); }
 };
+
+// A row-major operand tile stays row-major in LDS ([BK contraction rows][ROWS + 16]: 16-byte stores as loaded) and its fragments
+// come back through `ds_read_b64_tr_b16`, which hands lane (j = l & 15, g = l >> 4) the 4 x 4 transposed block it needs: two reads
+// give rows 8g .. 8g+7 (the contraction) of column c0 + j.  (First version: 2-byte transposing stores, 8 per piece -- the weight
+// gradient, whose two operands are both row-major, took 29 us for both mixers' in_proj at 1568 rows.)
+template <int ROWS> struct gm_rm {
+    static constexpr int LROW = ROWS + 16;          // 32 bytes of padding: the 4 rows x 32 bytes of a transpose read fall on distinct banks
+};
+typedef short gm_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) gm_v4s* gm_tr_ptr;
+typedef uint32_t gm_u32x2 __attribute__((ext_vector_type(2)));
 
 typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gm_f16x8 __attribute__((ext_vector_type(8)));
@@ -90,27 +101,32 @@ struct gm_tile {
         for (int p = 0; p < NP; ++p) {
             int row, k;
             where(tid + p * 256, row, k);
-            const int base = gm_lds<BK>::off(row, k);
-            if (KMAJOR) {
-                *reinterpret_cast<gm_u32x4*>(lds + base) = v[p];
-            } else {                                                         // rows row .. row + 7 share bits 3..: one swizzle for the piece
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {                                // 8 elements of 8 consecutive rows at one k: transposed by the stores
-                    lds[base + (2 * j) * gm_lds<BK>::LROW] = (uint16_t)(v[p][j] & 0xffffu);
-                    lds[base + (2 * j + 1) * gm_lds<BK>::LROW] = (uint16_t)(v[p][j] >> 16);
-                }
-            }
+            if (KMAJOR) *reinterpret_cast<gm_u32x4*>(lds + gm_lds<BK>::off(row, k)) = v[p];
+            else *reinterpret_cast<gm_u32x4*>(lds + k * gm_rm<ROWS>::LROW + row) = v[p];          // as loaded: [k][row .. row + 7]
         }
     }
 };
+
+// fragment of operand rows r0 + (l & 15), contraction kk + 8 (l >> 4) .. + 7, from either LDS image
+template <int ROWS, int BK, bool KMAJOR>
+__device__ __forceinline__ gm_u32x4 gm_frag(const uint16_t* lds, int r0, int kk, int fi, int fg) {
+    if constexpr (KMAJOR) {
+        return *reinterpret_cast<const gm_u32x4*>(lds + gm_lds<BK>::off(r0 + fi, kk + 8 * fg));
+    } else {
+        const uint16_t* q = lds + (kk + 8 * fg + (fi >> 2)) * gm_rm<ROWS>::LROW + r0 + 4 * (fi & 3);
+        const gm_v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gm_tr_ptr)q);
+        const gm_v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((gm_tr_ptr)(q + 4 * gm_rm<ROWS>::LROW));
+        const gm_u32x2 w0 = __builtin_bit_cast(gm_u32x2, a0), w1 = __builtin_bit_cast(gm_u32x2, a1);
+        return (gm_u32x4){w0.x, w0.y, w1.x, w1.y};
+    }
+}
 
 template <typename T, typename TC, int BM, int BN, int BK, bool AK, bool BKM>
 __global__ __launch_bounds__(256) void gemm_kernel(const mix_args<dm_gemm_args> pm) {
     const dm_gemm_args& p = pm.a[blockIdx.z];
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;       // wave tile and its 16 x 16 sub-tiles
-    constexpr int LROW = gm_lds<BK>::LROW;
-    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LROW];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LROW];
+    __shared__ __attribute__((aligned(16))) uint16_t As[AK ? BM * gm_lds<BK>::LROW : BK * gm_rm<BM>::LROW];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[BKM ? BN * gm_lds<BK>::LROW : BK * gm_rm<BN>::LROW];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
@@ -143,9 +159,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const mix_args<dm_gemm_args> 
         for (int kk = 0; kk < BK; kk += 32) {
             gm_u32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int j = 0; j < TM; ++j) fa[j] = *reinterpret_cast<const gm_u32x4*>(As + gm_lds<BK>::off(wm + 16 * j + fi, kk + 8 * fg));
+            for (int j = 0; j < TM; ++j) fa[j] = gm_frag<BM, BK, AK>(As, wm + 16 * j, kk, fi, fg);
 #pragma unroll
-            for (int i = 0; i < TN; ++i) fb[i] = *reinterpret_cast<const gm_u32x4*>(Bs + gm_lds<BK>::off(wn + 16 * i + fi, kk + 8 * fg));
+            for (int i = 0; i < TN; ++i) fb[i] = gm_frag<BN, BK, BKM>(Bs, wn + 16 * i, kk, fi, fg);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
