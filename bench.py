@@ -327,7 +327,7 @@ def install_route_a():
     Mamba.forward = forward
 
 
-def comm_accounting(step, model, ddp_net, graph_train, rank, world, grad_compression):
+def comm_accounting(step, model, ddp_net, graph_train, rank, world, grad_compression, gstep=None):
     """What the first real multi-GPU run needs to be read: the gradient bytes all-reduced per step, the number
     of collectives they travel in, and -- from ONE profiled step after the timed region, rank 0's own trace -- the device time of
     the RCCL kernels and how much of it was EXPOSED, i.e. not covered by any compute kernel running at the same time.
@@ -341,7 +341,13 @@ def comm_accounting(step, model, ddp_net, graph_train, rank, world, grad_compres
             "wire_dtype": {2: grad_compression, 4: "fp32"}[es], "world": world,
             # ring all-reduce = reduce-scatter + all-gather: every rank sends and receives 2 (N - 1) / N of the payload
             "bytes_on_the_wire_per_rank": int(2 * (world - 1) / max(world, 1) * nparam * es)}
-    if graph_train:
+    if graph_train and gstep is not None and getattr(gstep, "staged", None) is not None:
+        info["collectives_per_step"] = gstep.staged.nstage
+        info["bytes_per_collective"] = [int(f.numel() * 4) for f in gstep.flats]
+        info["schedule"] = (f"{gstep.staged.nstage} hipGraphs, one per group of {gstep.staged.per} blocks of the backward (the first also holds the forward); "
+                            "each group's all_reduce(AVG) is launched asynchronously right after its graph and runs on RCCL's stream under the next "
+                            "group's graph; the last one is exposed; then the AdamW + EMA graph")
+    elif graph_train:
         info["collectives_per_step"] = 1
         info["schedule"] = "graph 1 (forward + backward + flatten) | ONE all_reduce(AVG) of the flat fp32 gradient | graph 2 (AdamW + EMA): not overlapped"
     else:
@@ -528,7 +534,8 @@ def main():
     assert torch.isfinite(last.detach().float()).all(), "non-finite loss/sample in the timed region"
     comm = None
     if (world > 1 or force_ddp) and args.mode == "train":
-        comm = comm_accounting(step, model, net, args.graph, rank, world, os.environ.get("DIFFMA_GRAD_COMPRESSION", "none"))
+        comm = comm_accounting(step, model, net, args.graph, rank, world, os.environ.get("DIFFMA_GRAD_COMPRESSION", "none"),
+                               gstep if (args.graph and args.mode == "train") else None)
 
     if rank == 0:
         ksum = timer.summary()
@@ -592,7 +599,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 autocast (fp32 master weights, fp32 scan state)" if amp else "f32",
             "data": "synthetic (BASELINE.md section 4), random-init weights with zero-init tensors re-randomised",
-            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1 and not force_ddp) else (", step replayed from two hipGraphs around one gradient all-reduce" if args.graph else "")) if args.mode == "train"
+            "config": {"workload": f"{args.model} DDP training step, 4x28x28 latents (196 tokens), batch {B}/GPU" + (", whole step replayed from a hipGraph" if (args.graph and world == 1 and not force_ddp) else (", step replayed from hipGraphs around the gradient all-reduce(s)" if args.graph else "")) if args.mode == "train"
                        else f"{args.model} {'p_sample step (250-step respaced DDPM)' if args.sampler == 'ddpm250' else 'ddim_sample step (50-step DDIM)'}, batch {B}/GPU" + (", hipGraph replay" if args.graph else ""),
                        "global_batch": B * world, "seq_len": tokens, "parallelism": f"dp{world}",
                        "optimizer_steps_per_sec": round(args.steps / elapsed, 4), "gemm_tuning": args.gemm_tuning,

@@ -86,6 +86,108 @@ class GraphedDenoiser:
         return self.model.parameters()
 
 
+class StagedBackward:
+    """The backward of one DiffMa training loss in STAGES of `per` blocks, last blocks first, so that the gradients of a stage are
+    complete -- and can be all-reduced -- while the earlier blocks' backward still runs (GraphedTrainStep captures one hipGraph per
+    stage and launches each stage's all-reduce between replays; reference train.py:153 overlaps the same way through DDP's
+    buckets, which a captured backward cannot use).
+
+    autograd has no "stop here" for an interior tensor, so the cuts are made in the FORWARD: while `with staged:` is active, hooks
+    replace every block's output (and the conditioning vector c, and the embedded input of block 0) by a detached leaf that all
+    later consumers read -- the next block, and the long-skip partner (reference model.py:286-295: block i > depth/2 reads
+    outs[i-1] + outs[depth-1-i]).  The backward is then one `torch.autograd.backward(block output, grad_tensors=leaf.grad,
+    inputs=block parameters + the leaves the block read)` per block, last block first: by the time block j runs, every consumer of
+    its output has deposited its gradient in the leaf.  Parameter gradients accumulate in `.grad` exactly as with one `backward()`;
+    the arithmetic is the same, only the order in which the contributions to c (16 blocks + head) are added differs."""
+
+    def __init__(self, model, per=4):
+        self.model, self.depth, self.per = model, len(model.blocks), per
+        if self.depth < 2 * per or self.depth % per:
+            raise ValueError(f"staged backward needs depth ({self.depth}) to be a multiple of {per} and at least {2 * per}")
+        self.nstage = self.depth // per
+        blk_params = [[p for p in b.parameters() if p.requires_grad] for b in model.blocks]
+        in_blocks = {id(p) for ps in blk_params for p in ps}
+        rest = [p for p in model.parameters() if p.requires_grad and id(p) not in in_blocks]
+        tail = {id(p) for p in model.final_layer.parameters()}
+        self.blk_params = blk_params
+        self.head_params = [p for p in rest if id(p) in tail]
+        self.embed_params = [p for p in rest if id(p) not in tail]
+        self.params = []                                   # per stage, in the order the stages run (last blocks first)
+        for s in range(self.nstage - 1, -1, -1):
+            ps = [p for b in range(s * per, (s + 1) * per) for p in blk_params[b]]
+            if s == self.nstage - 1:
+                ps = ps + self.head_params
+            if s == 0:
+                ps = ps + self.embed_params
+            self.params.append(ps)
+        self._hooks = []
+
+    # ---- forward-side cuts ------------------------------------------------------------------------------------------------
+    def __enter__(self):
+        self.orig, self.leaf = [None] * self.depth, [None] * self.depth
+        self.c_orig = self.c_leaf = self.x0_orig = self.x0_leaf = None
+        cut = lambda t: t.detach().requires_grad_(True)
+
+        def pre(k):
+            def hook(m, args):
+                x, c = args[0], args[1]
+                if k == 0:
+                    self.c_orig, self.c_leaf = c, cut(c)
+                    self.x0_orig, self.x0_leaf = x, cut(x)
+                    x = self.x0_leaf
+                return (x, self.c_leaf) + tuple(args[2:])
+            return hook
+
+        def post(k):
+            def hook(m, args, out):
+                self.orig[k], self.leaf[k] = out, cut(out)
+                return self.leaf[k]
+            return hook
+
+        for k, b in enumerate(self.model.blocks):
+            self._hooks.append(b.register_forward_pre_hook(pre(k)))
+            self._hooks.append(b.register_forward_hook(post(k)))
+        self._hooks.append(self.model.final_layer.register_forward_pre_hook(lambda m, args: (args[0], self.c_leaf) + tuple(args[2:])))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        return False
+
+    def _reads(self, i):
+        """the leaves block i read: the chain activation and, past the middle of the stack, its long-skip partner"""
+        ins = [self.x0_leaf] if i == 0 else [self.leaf[i - 1]]
+        if i > self.depth / 2:
+            ins.append(self.leaf[self.depth - i - 1])
+        return ins
+
+    # ---- backward, stage by stage -----------------------------------------------------------------------------------------
+    def run_stage(self, k, loss=None):
+        """Stage k (0 = the LAST `per` blocks + the head; nstage - 1 = the first blocks + the embedders): afterwards the `.grad` of
+        self.params[k] is complete."""
+        s = self.nstage - 1 - k
+        if k == 0:
+            torch.autograd.backward(loss, inputs=self.head_params + [self.leaf[self.depth - 1], self.c_leaf], retain_graph=True)
+        for i in range((s + 1) * self.per - 1, s * self.per - 1, -1):
+            g = self.leaf[i].grad
+            if g is None:                                   # an output nobody consumed (cannot happen in DiffMa's wiring)
+                continue
+            torch.autograd.backward(self.orig[i], grad_tensors=g, inputs=self.blk_params[i] + self._reads(i) + [self.c_leaf], retain_graph=True)
+        if s == 0:
+            outs_, gs = [self.x0_orig, self.c_orig], [self.x0_leaf.grad, self.c_leaf.grad]
+            keep = [(o, g) for o, g in zip(outs_, gs) if g is not None and o.requires_grad]
+            if keep and self.embed_params:
+                torch.autograd.backward([o for o, _ in keep], grad_tensors=[g for _, g in keep], inputs=self.embed_params)
+
+    def run(self, loss, on_stage=None):
+        for k in range(self.nstage):
+            self.run_stage(k, loss)
+            if on_stage is not None:
+                on_stage(k)
+
+
 class GraphedTrainStep:
     """One whole optimisation step -- q_sample noise, denoiser forward, loss, backward, fused AdamW, EMA -- captured in
     ONE hipGraph and replayed per iteration.
@@ -109,7 +211,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, ema, optimizer, diffusion, z, t, y, y2, w, autocast_dtype=None, ema_decay=0.9999, warmup=3,
-                 process_group=None, split=None):
+                 process_group=None, split=None, stages=None):
         assert z.is_cuda, "graph capture needs a ROCm device"
         for g in optimizer.param_groups:
             if not g.get("capturable", False):
@@ -133,6 +235,16 @@ class GraphedTrainStep:
         self.split = bool(split) if split is not None else nranks > 1
         if self.split and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("the two-graph (data-parallel) step needs an initialised process group")
+        # Data-parallel form in STAGES (default when the model's wiring allows it): the backward is cut into groups of 4 blocks
+        # (StagedBackward), one hipGraph per group, and each group's gradients are all-reduced -- asynchronously, on RCCL's stream --
+        # while the next group's graph replays.  stages=0 keeps ONE all-reduce after the whole backward.
+        import os
+        if stages is None:
+            stages = int(os.environ.get("DIFFMA_GRAPH_STAGES", "4"))
+        self.staged = None
+        if self.split and stages and hasattr(model, "blocks") and hasattr(model, "final_layer") and len(model.blocks) >= 2 * 4 \
+                and len(model.blocks) % 4 == 0 and type(model.blocks[0]).__name__ == "Spiral_MambaBlock":
+            self.staged = StagedBackward(model, per=len(model.blocks) // max(2, min(int(stages), len(model.blocks) // 4)))
         self._gp = [p for p in model.parameters() if p.requires_grad]
         # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
         # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
@@ -146,7 +258,9 @@ class GraphedTrainStep:
             side.wait_stream(torch.cuda.current_stream(z.device))
             with torch.cuda.stream(side):
                 for _ in range(warmup):                   # lazy inits, GEMM solution lookups, optimizer state allocation
-                    if self.split:
+                    if self.staged is not None:
+                        self._staged_eager()
+                    elif self.split:
                         self._fwd_bwd()
                         self._all_reduce()
                         self._update()
@@ -156,7 +270,19 @@ class GraphedTrainStep:
             self.graph = torch.cuda.CUDAGraph()
             self.opt.zero_grad(set_to_none=True)
             mode = _capture_mode(z.device)
-            if self.split:
+            if self.staged is not None:
+                self.stage_graphs, self.flats = [], []
+                for k in range(self.staged.nstage):
+                    g = self.graph if k == 0 else torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode=mode, **({} if k == 0 else {"pool": self.graph.pool()})):
+                        if k == 0:
+                            self.sloss = self._staged_forward()
+                        self.flats.append(self._staged_stage(k))
+                    self.stage_graphs.append(g)
+                self.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
+                    self._update()
+            elif self.split:
                 with torch.cuda.graph(self.graph, capture_error_mode=mode):       # gradients are allocated inside the graph's pool and stay attached
                     self.sloss = self._fwd_bwd()
                 self.graph2 = torch.cuda.CUDAGraph()
@@ -207,22 +333,53 @@ class GraphedTrainStep:
         self.flat = torch.cat([g.reshape(-1).float() for g in grads])          # one buffer = one collective
         return loss.detach()
 
+    # ---- the data-parallel form in stages: graph k = backward of block group k (+ the forward in graph 0) | all-reduce k (async) ----
+    def _staged_forward(self):
+        with self.staged:
+            with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
+                self._staged_loss = self.diffusion.training_losses(self.model, self.sz, self.st, dict(y=self.sy, y2=self.sy2, w=self.sw))["loss"].mean()
+        return self._staged_loss.detach()
+
+    def _staged_stage(self, k):
+        self.staged.run_stage(k, self._staged_loss)
+        ps = self.staged.params[k]
+        return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
+
+    def _staged_eager(self):
+        import torch.distributed as dist
+        self._staged_forward()
+        self.flats = []
+        works = []
+        for k in range(self.staged.nstage):
+            self.flats.append(self._staged_stage(k))
+            works.append(dist.all_reduce(self.flats[k], op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+        for wk in works:
+            wk.wait()
+        self._update()
+
     def _all_reduce(self):
         import torch.distributed as dist
         dist.all_reduce(self.flat, op=dist.ReduceOp.AVG, group=self.pg)
 
     def _update(self):
         with torch.no_grad():
-            off = 0
-            for p in self._gp:                              # the averaged gradients back into the tensors the optimizer reads
-                n = p.numel()
-                g = self.flat[off:off + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.to(p.dtype).clone()
-                else:
-                    p.grad.copy_(g)
-                off += n
-            found = (~torch.isfinite(self.flat).all()).float()     # after the all-reduce: the same on every rank
+            if self.staged is not None:
+                groups = list(zip(self.staged.params, self.flats))
+            else:
+                groups = [(self._gp, self.flat)]
+            found = None
+            for ps, flat in groups:
+                off = 0
+                for p in ps:                                # the averaged gradients back into the tensors the optimizer reads
+                    n = p.numel()
+                    g = flat[off:off + n].view_as(p)
+                    if p.grad is None:
+                        p.grad = g.to(p.dtype).clone()
+                    else:
+                        p.grad.copy_(g)
+                    off += n
+                bad = (~torch.isfinite(flat).all()).float()         # after the all-reduce: the same on every rank
+                found = bad if found is None else torch.maximum(found, bad)
         self._guarded_update(found)
 
     def step(self, z, t, y, y2, w):
@@ -232,10 +389,20 @@ class GraphedTrainStep:
         self.sy2.copy_(y2)
         self.sw.copy_(w)
         with torch.cuda.device(self.sz.device):
-            self.graph.replay()
-            if self.split:
-                self._all_reduce()
+            if self.staged is not None:
+                import torch.distributed as dist
+                works = []
+                for g, flat in zip(self.stage_graphs, self.flats):      # all-reduce k rides on RCCL's stream under graph k + 1
+                    g.replay()
+                    works.append(dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=True))
+                for wk in works:
+                    wk.wait()
                 self.graph2.replay()
+            else:
+                self.graph.replay()
+                if self.split:
+                    self._all_reduce()
+                    self.graph2.replay()
         # a replayed optimizer updates A_log without bumping its version counter: drop the mixers' no-grad cache of -exp(A_log)
         for m in self._mixers:
             m.__dict__.pop("_A_cache", None)

@@ -349,7 +349,7 @@ def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
     assert d["config"]["world_size_seen_by_rccl"] == 1 and d["config"]["parallelism"].startswith("dp1")
     assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["roofline"]["kernel"].startswith("dm_")        # (at this test's 4 samples the projections' dm_gemm can outweigh the scans)
-    assert ("two hipGraphs" in d["config"]["workload"]) == graph
+    assert ("hipGraphs around the gradient all-reduce" in d["config"]["workload"]) == graph
 
 
 def test_graphed_train_step_two_graphs_equal_one_graph(gpu, monkeypatch):
@@ -399,3 +399,60 @@ def test_graphed_train_step_two_graphs_equal_one_graph(gpu, monkeypatch):
     assert all(l == l for l in l1) and l1 == l2, (l1, l2)
     for a, b in zip(p1 + e1, p2 + e2):
         torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_graphed_train_step_in_stages_matches_one_all_reduce(gpu, monkeypatch):
+    """The data-parallel graphed step with the backward cut into block groups (graphed.StagedBackward: one hipGraph per group, each
+    group's all-reduce launched asynchronously between replays) against the two-graph form with ONE all-reduce, on a one-rank
+    process group: same losses, weights and EMA to rounding (the contributions to the conditioning vector's gradient are added in
+    another order) after 6 steps, fp32 and bf16 autocast."""
+    import copy
+    import socket
+
+    import torch.distributed as dist
+
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.graphed import GraphedTrainStep
+    from diffma_amd.model import DiffMa
+
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        _dist_env(monkeypatch, port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=gpu)
+    torch.manual_seed(23)
+    net0 = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=8, d_state=16).to(gpu)
+    with torch.no_grad():
+        for p in net0.parameters():
+            if float(p.abs().max()) == 0.0:
+                p.normal_(0, 0.02)
+    B = 4
+    mk = lambda *sh: torch.randn(*sh, device=gpu)
+    x, y, y2, w = mk(B, 4, 8, 8), mk(B, 64), mk(B, 16, 64), torch.sigmoid(mk(B, 16, 1))
+    d = create_diffusion("")
+
+    for amp, tol in ((None, 1e-4), (torch.bfloat16, 3e-2)):
+        def run(stages):
+            torch.manual_seed(11)
+            net = copy.deepcopy(net0).train()
+            ema = copy.deepcopy(net).requires_grad_(False)
+            opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0, fused=True, capturable=True)
+            gs = GraphedTrainStep(net, ema, opt, d, x, torch.zeros(B, device=gpu, dtype=torch.long), y, y2, w, autocast_dtype=amp,
+                                  ema_decay=0.9, warmup=2, split=True, stages=stages)
+            assert (gs.staged is not None) == bool(stages)
+            if stages:
+                assert gs.staged.nstage == 2 and len(gs.stage_graphs) == 2
+            tg = torch.Generator(device=gpu).manual_seed(5)
+            losses = [float(gs.step(x, torch.randint(0, d.num_timesteps, (B,), device=gpu, generator=tg), y, y2, w)) for _ in range(6)]
+            return losses, [p.detach().clone() for p in net.parameters()], [p.detach().clone() for p in ema.parameters()]
+
+        l1, p1, e1 = run(0)
+        l2, p2, e2 = run(4)
+        assert all(l == l for l in l1 + l2)
+        for a, b in zip(l1, l2):
+            assert abs(a - b) <= tol * max(1.0, abs(a)), (l1, l2)
+        num = sum(float((a - b).float().norm() ** 2) for a, b in zip(p1 + e1, p2 + e2)) ** 0.5
+        den = sum(float(a.float().norm() ** 2) for a in p1 + e1) ** 0.5
+        assert num / den <= tol, num / den

@@ -354,3 +354,54 @@ def test_step_prep_shadows_survive_two_forwards_and_a_retained_graph():
     import gc
     gc.collect()
     assert key not in step_prep._SHADOWS
+
+
+def test_staged_backward_equals_one_backward():
+    """graphed.StagedBackward: the loss's backward in 4 stages of blocks (last first, `torch.autograd.grad` with the chain / long-skip
+    activations and the conditioning vector as cut tensors) must give every parameter the gradient one `backward()` gives it --
+    depth 8 (two stages of 4, skips across the cut) and depth 12 (three stages)."""
+    import diffma_amd.mamba as mamba_mod
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.graphed import StagedBackward
+    from diffma_amd.model import DiffMa
+
+    real = mamba_mod.spiral_ssm
+    mamba_mod.spiral_ssm = _oracle_spiral_ssm                     # test-only substitution (see module docstring)
+    try:
+        for depth in (8, 12):
+            torch.manual_seed(depth)
+            net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=32, depth=depth, d_state=16).train()
+            with torch.no_grad():
+                for p in net.parameters():
+                    if p.requires_grad and float(p.abs().max()) == 0.0:
+                        p.copy_(torch.randn_like(p) * 0.05)
+            B, T = 2, 16
+            z, y, y2 = torch.randn(B, 4, 8, 8), torch.randn(B, 32), torch.randn(B, T, 32)
+            w = torch.sigmoid(torch.randn(B, T, 1))
+            t = torch.tensor([3, 700])
+            nz = torch.randn(B, 4, 8, 8)
+            d = create_diffusion("")
+            loss = d.training_losses(net, z, t, dict(y=y, y2=y2, w=w), noise=nz)["loss"].mean()
+            loss.backward()
+            ref = {id(p): p.grad.clone() for p in net.parameters() if p.grad is not None}
+            net.zero_grad(set_to_none=True)
+            sb = StagedBackward(net, per=4)
+            with sb:
+                loss = d.training_losses(net, z, t, dict(y=y, y2=y2, w=w), noise=nz)["loss"].mean()
+            seen = []
+            sb.run(loss, on_stage=lambda k: seen.append(k))
+            assert seen == list(range(depth // 4))
+            n = 0
+            for ps in sb.params:
+                for p in ps:
+                    torch.testing.assert_close(p.grad, ref[id(p)], rtol=1e-4, atol=1e-6)
+                    n += 1
+            assert n == len(ref)
+            # the hooks are gone: an ordinary forward + backward works again
+            net.zero_grad(set_to_none=True)
+            d.training_losses(net, z, t, dict(y=y, y2=y2, w=w), noise=nz)["loss"].mean().backward()
+            for p in net.parameters():
+                if p.requires_grad:
+                    torch.testing.assert_close(p.grad, ref[id(p)], rtol=1e-5, atol=1e-7)
+    finally:
+        mamba_mod.spiral_ssm = real
