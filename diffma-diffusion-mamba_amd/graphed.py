@@ -235,12 +235,15 @@ class GraphedTrainStep:
         self.split = bool(split) if split is not None else nranks > 1
         if self.split and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("the two-graph (data-parallel) step needs an initialised process group")
-        # Data-parallel form in STAGES (default when the model's wiring allows it): the backward is cut into groups of 4 blocks
+        # Data-parallel form in STAGES (opt-in: stages=4 / DIFFMA_GRAPH_STAGES=4): the backward is cut into groups of blocks
         # (StagedBackward), one hipGraph per group, and each group's gradients are all-reduced -- asynchronously, on RCCL's stream --
-        # while the next group's graph replays.  stages=0 keeps ONE all-reduce after the whole backward.
+        # while the next group's graph replays.  Default 0 = ONE all-reduce after the whole backward: on one rank the staged form
+        # costs +1.15 ms at one sample per GPU and +0.4 ms at batch 8 (per-block autograd calls re-walk the nodes the blocks share,
+        # three more graph launches and collectives), about what hiding three quarters of a ~0.7 ms all-reduce would return on
+        # 8 GPUs -- it has to be measured there before it becomes the default.
         import os
         if stages is None:
-            stages = int(os.environ.get("DIFFMA_GRAPH_STAGES", "4"))
+            stages = int(os.environ.get("DIFFMA_GRAPH_STAGES", "0"))
         self.staged = None
         if self.split and stages and hasattr(model, "blocks") and hasattr(model, "final_layer") and len(model.blocks) >= 2 * 4 \
                 and len(model.blocks) % 4 == 0 and type(model.blocks[0]).__name__ == "Spiral_MambaBlock":
@@ -368,6 +371,7 @@ class GraphedTrainStep:
             else:
                 groups = [(self._gp, self.flat)]
             found = None
+            dst, src = [], []
             for ps, flat in groups:
                 off = 0
                 for p in ps:                                # the averaged gradients back into the tensors the optimizer reads
@@ -376,10 +380,13 @@ class GraphedTrainStep:
                     if p.grad is None:
                         p.grad = g.to(p.dtype).clone()
                     else:
-                        p.grad.copy_(g)
+                        dst.append(p.grad)
+                        src.append(g)
                     off += n
                 bad = (~torch.isfinite(flat).all()).float()         # after the all-reduce: the same on every rank
                 found = bad if found is None else torch.maximum(found, bad)
+            if dst:
+                torch._foreach_copy_(dst, src)              # ONE multi-tensor launch (per-parameter copy_ was 459 launches per step)
         self._guarded_update(found)
 
     def step(self, z, t, y, y2, w):

@@ -39,6 +39,8 @@ class _NegExpAll(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, *logs):
+        ctx.set_materialize_grads(False)       # a staged backward (graphed.StagedBackward) asks for two of the outputs' gradients at a time:
+                                               # without this autograd would fill a zero tensor for each of the others on every call
         outs = torch._foreach_exp([a.float() if a.dtype != torch.float32 else a for a in logs])
         torch._foreach_neg_(outs)
         ctx.save_for_backward(*outs)
