@@ -590,6 +590,12 @@ def main():
                 traffic_src = f"{tsrc} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes at this shape; not re-measured in this run)"
         valu = load_profile_valu(dom, args.dtype) if (args.model == "DiffMa-L/2" and not args.use_mamba2) else None
         design_per_launch = r["design_bytes_per_launch"] / (r["avg_us"] * 1e-6) / 1e9 * conc
+        mfma_roof = None
+        if r.get("flops_per_launch", 0) > 0:             # a matrix-pipe kernel dominates (dm_gemm at small batches): its roof is the MFMA peak
+            tf = r["flops_per_launch"] / (r["avg_us"] * 1e-6) / 1e12 * conc
+            mfma_roof = {"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                         "flops_per_launch": int(r["flops_per_launch"]),
+                         "note": "launch-bound regime: a few hundred workgroups of a 64 x 64 tile per launch, both mixers of a block in one launch"}
         res = {
             "metric": f"diffusion-steps/sec ({args.model}{' mamba2' if args.use_mamba2 else ''}, 224x224, {'training' if args.mode == 'train' else ('250-step DDPM sampling' if args.sampler == 'ddpm250' else '50-step DDIM sampling')}; samples*steps/s)",
             "value": round(args.steps * B * world / elapsed, 3),
@@ -628,6 +634,8 @@ def main():
                                    "opt-in two-stream mode DIFFMA_OVERLAP_MIXERS=1 lets launches of the two mixers share the GPU)"},
             "kernels": kernels,
         }
+        if mfma_roof is not None:
+            res["roofline"].update(mfma_roof, limiter="launch / latency", hbm_view={k: res["roofline"][k] for k in ("achieved", "peak", "unit", "frac")})
         _log(f"timed region done: {1e3 * elapsed / args.steps:.1f} ms/step")
         res["config"]["world_size_seen_by_rccl"] = dist.get_world_size() if dist.is_initialized() else 1
         if comm is not None:

@@ -40,13 +40,13 @@ class KernelTimer:
     def __init__(self):
         self.records = {}      # name -> list of (start_event, end_event, algorithmic_bytes, design_bytes)
 
-    def launch(self, name, nbytes, fn, design_bytes=None):
+    def launch(self, name, nbytes, fn, design_bytes=None, flops=0):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        self.records.setdefault(name, []).append((e0, e1, nbytes, nbytes if design_bytes is None else design_bytes))
+        self.records.setdefault(name, []).append((e0, e1, nbytes, nbytes if design_bytes is None else design_bytes, flops))
 
     def summary(self):
         """Per kernel: launches, avg_us / total_ms (per-launch durations, what a kernel trace reports), bytes_per_launch, and
@@ -65,7 +65,8 @@ class KernelTimer:
             db = [r[3] for r in recs]
             busy = union_length((base.elapsed_time(r[0]), base.elapsed_time(r[0]) + d) for r, d in zip(recs, ms))
             out[name] = dict(launches=len(recs), avg_us=1e3 * sum(ms) / len(ms), total_ms=sum(ms),
-                             bytes_per_launch=sum(nb) / len(nb), design_bytes_per_launch=sum(db) / len(db), busy_ms=busy)
+                             bytes_per_launch=sum(nb) / len(nb), design_bytes_per_launch=sum(db) / len(db), busy_ms=busy,
+                             flops_per_launch=sum(r[4] for r in recs) / len(recs))
         return out
 
 
@@ -122,11 +123,12 @@ class paired:
         k = self.mark
         if pairwise and not self.broken and k is not None and len(q) == 2 * k and all(q[i][0] == q[i + k][0] for i in range(k)):
             for i in range(k):
-                name, a0, tensor, nbytes, design = q[i]
-                _issue(name, [a0, q[i + k][1]], tensor, nbytes + q[i + k][3], None if design is None else design + (q[i + k][4] or 0))
+                name, a0, tensor, nbytes, design, flops = q[i]
+                _issue(name, [a0, q[i + k][1]], tensor, nbytes + q[i + k][3], None if design is None else design + (q[i + k][4] or 0),
+                       flops + q[i + k][5])
         else:
-            for name, a, tensor, nbytes, design in q:
-                _issue(name, [a], tensor, nbytes, design)
+            for name, a, tensor, nbytes, design, flops in q:
+                _issue(name, [a], tensor, nbytes, design, flops)
         self.keep = []
         self.mark = None
 
@@ -144,7 +146,7 @@ def _pair_flush():
 _DEBUG_SYNC = os.environ.get("DIFFMA_DEBUG_SYNC", "0") == "1"      # developer aid: synchronise and name every C-ABI launch
 
 
-def _issue(name, arg_list, tensor, nbytes, design_bytes):
+def _issue(name, arg_list, tensor, nbytes, design_bytes, flops=0):
     if _DEBUG_SYNC:
         print(f"[hip_ops] {name} x{len(arg_list)}", flush=True)
     with torch.cuda.device(tensor.device):
@@ -159,18 +161,19 @@ def _issue(name, arg_list, tensor, nbytes, design_bytes):
         if _TIMER is None:
             fn()
         else:
-            _TIMER.launch(name, nbytes, fn, design_bytes)
+            _TIMER.launch(name, nbytes, fn, design_bytes, flops)
         if _DEBUG_SYNC:
             torch.cuda.synchronize()
 
 
-def _launch(name, args, tensor, nbytes, design_bytes=None):
+def _launch(name, args, tensor, nbytes, design_bytes=None, flops=0):
     """nbytes: ALGORITHMIC bytes of the launch (SURVEY.md 8d: what any implementation of the operator must move);
-    design_bytes: the bytes THIS implementation moves by design (algorithmic + checkpoints + partial rows), if different."""
+    design_bytes: the bytes THIS implementation moves by design (algorithmic + checkpoints + partial rows), if different;
+    flops: for the matrix-pipe kernels whose roof is the MFMA peak (dm_gemm)."""
     if _PAIR is not None and not _PAIR.broken:
-        _PAIR.queue.append((name, args, tensor, nbytes, design_bytes))
+        _PAIR.queue.append((name, args, tensor, nbytes, design_bytes, flops))
         return
-    _issue(name, [args], tensor, nbytes, design_bytes)
+    _issue(name, [args], tensor, nbytes, design_bytes, flops)
 
 
 def dtype_code(t: torch.Tensor) -> int:
@@ -770,7 +773,7 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, out=None, out_dtype=None, accumulat
     g.accumulate = int(bool(accumulate))
     g.a, g.b, g.c = _ptr(a), _ptr(b), _ptr(out)
     g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
-    _launch("dm_gemm", g, a, (P * Kc + Q * Kc) * a.element_size() + P * Q * out.element_size())
+    _launch("dm_gemm", g, a, (P * Kc + Q * Kc) * a.element_size() + P * Q * out.element_size(), flops=2 * P * Q * Kc)
     return out
 
 
