@@ -216,10 +216,16 @@ static void gemm_launch_l(const dm_gemm_args& a, hipStream_t st) {
 
 template <typename T, typename TC>
 static void gemm_launch_t(const dm_gemm_args& a, hipStream_t st) {
-    // tile by the size of the grid: 128 x 64 (BK 64) once that still gives every CU a few workgroups, else 64 x 64 with BK 128
-    static const int force = [] { const char* e = getenv("DM_GEMM_TILE"); return e ? atoi(e) : 0; }();      // developer override: 1 small, 2 big
-    const int64_t wg_big = (int64_t)((a.P + 127) / 128) * ((a.Q + 63) / 64);
-    if ((wg_big >= 512 && force != 1) || force == 2) gemm_launch_l<T, TC, 128, 64, 64>(a, st);
+    // Tile by the size of the grid (both mixers counted when a second struct is announced): the largest tile that still gives every CU
+    // a workgroup -- these launches are bound by the L2 -> CU traffic of their operands (a 64 x 64 tile uses a loaded byte for 64
+    // multiply-adds, a 128 x 128 tile for 128), not by the matrix pipe.  64 x 64 (BK 128) is the fallback for the smallest grids.
+    static const int force = [] { const char* e = getenv("DM_GEMM_TILE"); return e ? atoi(e) : 0; }();      // developer override: 1 / 2 / 3
+    const int64_t n = mix_peek() ? 2 : 1;
+    auto wgs = [&](int bm, int bn) { return n * (int64_t)((a.P + bm - 1) / bm) * ((a.Q + bn - 1) / bn); };
+    int pick = force;
+    if (!pick) pick = wgs(128, 128) >= 256 ? 3 : (wgs(128, 64) >= 256 ? 2 : 1);
+    if (pick == 3) gemm_launch_l<T, TC, 128, 128, 64>(a, st);
+    else if (pick == 2) gemm_launch_l<T, TC, 128, 64, 64>(a, st);
     else gemm_launch_l<T, TC, 64, 64, 128>(a, st);
 }
 

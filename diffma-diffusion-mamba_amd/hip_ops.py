@@ -97,11 +97,10 @@ class paired:
         self.queue, self.keep, self.broken, self.mark = [], [], False, None
 
     def __enter__(self):
-        global _PAIR
         if self.enabled:
-            if _PAIR is not None:
+            if _pair() is not None:
                 raise RuntimeError("hip_ops.paired() does not nest")
-            _PAIR = self
+            _TLS.pair = self
         return self
 
     def second(self):
@@ -109,10 +108,9 @@ class paired:
         self.mark = len(self.queue)
 
     def __exit__(self, et, ev, tb):
-        global _PAIR
         if not self.enabled:
             return False
-        _PAIR = None
+        _TLS.pair = None
         if et is None:
             self.flush(pairwise=True)
         self.queue, self.keep = [], []
@@ -133,14 +131,21 @@ class paired:
         self.mark = None
 
 
-_PAIR = None
+import threading
+
+_TLS = threading.local()          # the queue belongs to the thread that opened it: the backward runs on autograd's worker thread
+
+
+def _pair():
+    return getattr(_TLS, "pair", None)
 
 
 def _pair_flush():
     """A wrapper is about to do torch arithmetic on launch outputs: issue what is queued (unpaired) and stop queueing."""
-    if _PAIR is not None:
-        _PAIR.flush()
-        _PAIR.broken = True
+    pr = _pair()
+    if pr is not None:
+        pr.flush()
+        pr.broken = True
 
 
 _DEBUG_SYNC = os.environ.get("DIFFMA_DEBUG_SYNC", "0") == "1"      # developer aid: synchronise and name every C-ABI launch
@@ -170,8 +175,9 @@ def _launch(name, args, tensor, nbytes, design_bytes=None, flops=0):
     """nbytes: ALGORITHMIC bytes of the launch (SURVEY.md 8d: what any implementation of the operator must move);
     design_bytes: the bytes THIS implementation moves by design (algorithmic + checkpoints + partial rows), if different;
     flops: for the matrix-pipe kernels whose roof is the MFMA peak (dm_gemm)."""
-    if _PAIR is not None and not _PAIR.broken:
-        _PAIR.queue.append((name, args, tensor, nbytes, design_bytes, flops))
+    pr = _pair()
+    if pr is not None and not pr.broken:
+        pr.queue.append((name, args, tensor, nbytes, design_bytes, flops))
         return
     _issue(name, [args], tensor, nbytes, design_bytes, flops)
 
@@ -198,8 +204,9 @@ def _stream(t: torch.Tensor) -> int:
 def _ptr(t):
     if t is None:
         return 0
-    if _PAIR is not None:
-        _PAIR.keep.append(t)           # the launch is deferred: the tensor must outlive the wrapper call that named it
+    pr = _pair()
+    if pr is not None:
+        pr.keep.append(t)              # the launch is deferred: the tensor must outlive the wrapper call that named it
     return t.data_ptr()
 
 
