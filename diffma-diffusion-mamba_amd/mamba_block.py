@@ -29,13 +29,17 @@ def _silu_once(c, dtype):
     import weakref
 
     ent = _SILU_ONCE[0]
-    grad = torch.is_grad_enabled()
+    grad = torch.is_grad_enabled() and c.requires_grad
     if ent is not None and ent[0]() is c and ent[1] == c._version and ent[2] == dtype and ent[3] == grad:
-        return ent[4]
+        out = ent[4]() if grad else ent[4]
+        if out is not None:
+            return out
     out = torch.nn.functional.silu(c)
     if out.dtype != dtype:
         out = out.to(dtype)
-    _SILU_ONCE[0] = (weakref.ref(c), c._version, dtype, grad, out)
+    # With a graph attached the cache holds the result WEAKLY: the blocks' autograd nodes keep it alive until the backward has run,
+    # after which a later call with the same tensor recomputes instead of handing out a result whose graph has been freed.
+    _SILU_ONCE[0] = (weakref.ref(c), c._version, dtype, grad, weakref.ref(out) if grad else out)
     return out
 
 
