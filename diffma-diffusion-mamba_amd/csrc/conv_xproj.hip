@@ -15,6 +15,7 @@
 //                v_mfma_f32_16x16x32_{bf16,f16}, fp32 accumulation, one 16 x 16 output tile per wave and row tile.
 // Two LDS tile buffers alternate, so there is one barrier per tile.  Algorithmic bytes: 2*s per element and direction (read
 // x, write x~) + the x_dbl rows.
+#include <cstdlib>
 #include <type_traits>
 #include "dm_common.h"
 
@@ -493,12 +494,299 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
     }
 }
 
+// ====================================================================================================================
+// K4x, slab form (round 4) -- the same operator for the mixer's call pattern (DM_FLAG_DX_MERGED, width 4, SiLU, row tables) when the
+// sequence is short enough for the running sum of dx to LIVE IN LDS: seqlen <= 256 (DiffMa-*/2 at 224 px: 196 tokens).
+//
+// The kernel above gives a workgroup a whole sample: 1024 channels x 196 tokens of dx do not fit on chip, so directions 1 and 2
+// read-add-store the token-order buffer in HBM (two extra reads and two extra writes of [B, L, D]) -- 1.96 GB per launch at the
+// bench batch, which at 510 us is the 3.9 TB/s an HBM-bound pass gets here.  This one cuts the sample into SLABS of 128 channels:
+//   workgroup = (sample, slab), 8 waves;  LDS: acc[L][128] 16-bit in TOKEN order (49 KB at L = 196) + one fp32 product tile per wave;
+//   every direction adds its dx rows into acc (the rounding of the running sum is the old kernel's, step for step), a barrier
+//   separates the directions, and dx leaves ONCE, as 16-byte pieces.  Traffic: du 3x, x 1x from HBM (its two re-reads come from
+//   L2: the slab is 49 KB and the workgroup is back within microseconds), dx 1x: 1.06 GB.
+// A lane still owns one channel PAIR for the conv (64 lanes = the slab), so the 8 waves cut the gathered sequence into 8 SEGMENTS
+// of ceil(L / 8) rows: the conv backward needs the gradient of the 3 rows after a segment, which the wave recomputes (28 rows of
+// work for 25 at L = 196).  Rows are processed in tiles of 16 (the MFMA M) from the end of the segment to its start; the product
+// tile d x_dbl . Wx goes through the wave's own LDS tile (no workgroup barrier inside a direction).  The x_proj.weight^T
+// fragments of the slab (64 VGPRs) and two register sets of prefetched rows (x, du, d x_dbl) fit because LDS, not VGPRs, bounds
+// the occupancy here (8 waves per CU, 256 VGPRs each): the loads of tile t+1 are issued before tile t's rows are touched.
+// The arithmetic is written on float2 (the lane's two channels): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.
+constexpr int XS_CS = 128;                 // channels per workgroup
+constexpr int XS_NW = 8;                   // waves = segments of the gathered sequence
+constexpr int XS_THREADS = XS_NW * WAVE;
+constexpr int XS_MAXL = 256;               // acc rows (+ 1 dummy row that takes the stores of rows a wave does not own)
+constexpr int XS_ROWP = XS_CS + 4;         // fp32 product tile row stride (rows 4g + r of a D-fragment on disjoint banks)
+constexpr int XS_MAXDIR = 4;
+constexpr int XS_SLOTS = ((XS_MAXL / XS_NW + 3 + XP_TM - 1) / XP_TM) * XP_TM;     // rows a wave walks per direction (whole tiles)
+// Per (direction, row slot) of a wave.  `own` comes FIRST: it multiplies a float2 as a broadcast of the LOW dword of the pair the
+// table read returns (op_sel_hi).  With acc_off first the compiler broadcasts the HIGH dword (op_sel:[1,0], or a v_mov into the low
+// register right in front of the v_pk_mul), and on MI355X that form gave the last 16 lanes a stale value for their first channel
+// now and then -- single rows missing from dw / db in a few channels (tools/dbg_k4x2.py; ROCm 7.2 hipcc).
+struct xs_row { float own; uint32_t acc_off; };
+
+template <typename T> struct xs_pair;      // the lane's two 16-bit channels <-> float2
+template <> struct xs_pair<bf16_t> {
+    static __device__ __forceinline__ f32x2 up(uint32_t w) { return (f32x2){__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)}; }
+};
+template <> struct xs_pair<f16_t> {
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ f32x2 up(uint32_t w) { return __builtin_convertvector(__builtin_bit_cast(h2, w), f32x2); }
+};
+
+__device__ __forceinline__ int64_t xs_uniform64(int64_t v) {      // a wave-uniform value back in SGPRs
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <typename T> struct xs_bufs {     // one tile's prefetched rows
+    uint32_t x[XP_TM + 3];                 // x rows l0-3 .. l0+15 (gathered), the lane's channel pair
+    uint32_t du[XP_TM];
+    xp_u32x4 a[2];                         // d x_dbl rows l0 .. l0+15 as MFMA A-fragments
+};
+
+template <typename T, typename TW>
+__global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(const dm_conv_xproj_bwd_args p) {
+    constexpr int W = 4, KP = 64, NT = XS_CS / 16, ES = (int)sizeof(T), NXR = XP_TM + W - 1, AW = XS_CS / 2, HR = XP_TM / 2;
+    __shared__ __attribute__((aligned(16))) uint32_t accs[(XS_MAXL + 1) * AW];
+    __shared__ __attribute__((aligned(16))) float ptile[XS_NW][XP_TM * XS_ROWP];
+    __shared__ __attribute__((aligned(16))) xp_u32x4 bfl[NT * 2 * WAVE];          // x_proj.weight^T of the slab in MFMA B-fragment order
+    __shared__ __attribute__((aligned(8))) xs_row rowtab[XS_NW][XS_MAXDIR * XS_SLOTS];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g = lane >> 4, ij = lane & 15;
+    const int L = p.seqlen, nslab = p.dim / XS_CS;
+    // workgroup -> (sample, slab): workgroups are dealt to the 8 XCDs round-robin; the slabs of one sample go to ONE XCD, so its
+    // d x_dbl rows (read by every slab) and the row tables are fetched into one L2, and the 8 x 256-byte pieces of a du row are
+    // requested close together in time
+    int b, slab;
+    {
+        const int i = (int)blockIdx.x;
+        if ((p.batch & 7) == 0) { const int q = i >> 3; slab = q % nslab; b = (q / nslab) * 8 + (i & 7); }
+        else { b = i / nslab; slab = i % nslab; }
+    }
+    const int c0 = slab * XS_CS, c = c0 + 2 * lane;
+    {   // the running sum starts at zero: direction 0 adds like the others
+        const xp_u32x4 z = {0u, 0u, 0u, 0u};
+        for (int q = tid; q < L * (AW / 4); q += XS_THREADS) reinterpret_cast<xp_u32x4*>(accs)[q] = z;
+    }
+    const rsrc_t r_x = make_rsrc_2g((const T*)p.x + (int64_t)b * p.x_sb + c0);      // (bounded: an offset of BIO_OOB loads nothing)
+    const rsrc_t r_wt = make_rsrc((const T*)p.wxt + (int64_t)c0 * KP);
+    const int vo = 2 * lane * ES;
+    const int sl_x = (int)p.x_sl * ES, sl_du = (int)p.du_sl * ES, sr_xd = (int)p.xd_sr * ES;
+
+    // x_proj.weight^T of the slab as B-fragments, parked in LDS in fragment order (wave n fetches column tile n): lane (g, j) of
+    // fragment (n, kk) holds wxt[c0 + 16 n + j][32 kk + 8g .. +7].  (In registers they are 64 VGPRs: with two sets of prefetched
+    // rows the kernel then spills.)
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_wt, ((wave * 16 + ij) * KP + 32 * kk + 8 * g) * ES, 0, 0);
+        bfl[(wave * 2 + kk) * WAVE + lane] = (xp_u32x4){q[0], q[1], q[2], q[3]};
+    }
+    f32x2 w[W], bias, dw[W], db, gnext[W - 1];            // gnext[k] = gradient of row (end of the half in work) + k: the rows done before
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+        w[k] = (f32x2){io<TW>::ld((const TW*)p.weight + (int64_t)c * W + k), io<TW>::ld((const TW*)p.weight + (int64_t)(c + 1) * W + k)};
+        dw[k] = (f32x2){0.f, 0.f};
+    }
+    bias = p.bias ? (f32x2){io<TW>::ld((const TW*)p.bias + c), io<TW>::ld((const TW*)p.bias + c + 1)} : (f32x2){0.f, 0.f};
+    db = (f32x2){0.f, 0.f};
+
+    // this wave's segment [a, e) of every gathered sequence; every wave runs the same number of tiles (a wave whose segment lies
+    // past the end works on masked rows: only sequences shorter than 8 x 13 rows have such waves)
+    const int seg = (L + XS_NW - 1) / XS_NW;
+    const int a = wave * seg;
+    const int e = (a + seg < L) ? a + seg : L;
+    const int nt = (seg + (W - 1) + XP_TM - 1) / XP_TM;
+    const int nsteps = p.ndir * nt;
+    float* const pt = ptile[wave];
+    // where the dx of (direction, row slot) goes and whether the row counts for dw / db: this wave's rows add to their token's row of
+    // acc, the rows it only recomputes (the 3 after its segment, the rest of the tile) store to a dummy row
+    xs_row* const rt = rowtab[wave];
+    for (int q = lane; q < p.ndir * nt * XP_TM; q += WAVE) {
+        const int dir = q / (nt * XP_TM), l = a + q % (nt * XP_TM);
+        const bool own = l < e;
+        rt[q].acc_off = (uint32_t)((own ? p.row_index[dir * L + l] : XS_MAXL) * AW * 4);
+        rt[q].own = own ? 1.0f : 0.0f;
+    }
+    const int du_bytes = (L - 1) * sl_du + XS_CS * ES;   // a du / d x_dbl row past the end of the sequence is out of the descriptor's range:
+    const int xd_bytes = L * sr_xd;                       // it loads as ZERO, and with it the gradient of the row
+
+    // loads of step (dir, t): rows l0 = a + 16 t ..
+    // per-direction bases advance by ADDITION (a 64-bit multiply by the direction is moved to the vector unit by the compiler, and
+    // every address derived from it then needs a waterfall loop)
+    const int64_t du_step = xs_uniform64((int64_t)p.batch * p.du_ss), xd_step = xs_uniform64((int64_t)p.batch * L * p.xd_sr);
+    const T* const du0 = (const T*)p.du + xs_uniform64((int64_t)b * p.du_ss + c0);
+    const T* const xd0 = (const T*)p.dxdbl + xs_uniform64((int64_t)b * L * p.xd_sr);
+    // `live` false (after the last tile): the same instructions with an out-of-range lane offset -- they load nothing, and the
+    // number of loads in flight stays what the compiler's s_waitcnt bookkeeping assumes on every path (a branch around the loads
+    // makes it wait for the NEW loads wherever it has to wait for an old one: no prefetch left)
+    auto issue = [&](int dir, int t, bool live, xs_bufs<T>& o) {
+        const int l0 = a + XP_TM * t;
+        const int vo_l = live ? vo : BIO_OOB;
+        const T* dup = du0;
+        const T* xdp = xd0;
+        for (int k = 0; k < dir; ++k) { dup += du_step; xdp += xd_step; }
+        const cptr<int32_t> idx = as_const(p.row_index + dir * L);
+        const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dup), 0, du_bytes, 0x00020000);
+        const rsrc_t r_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xdp), 0, xd_bytes, 0x00020000);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, live ? (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES : BIO_OOB, 0, 0);
+            o.a[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
+        }
+#pragma unroll
+        for (int j = NXR - 1; j >= 0; --j) {
+            const int lr = l0 - (W - 1) + j;
+            o.x[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo_l, idx[lr < 0 ? 0 : (lr < L ? lr : L - 1)] * sl_x, 0);
+        }
+#pragma unroll
+        for (int j = XP_TM - 1; j >= 0; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
+    };
+    // one tile: product on the matrix pipe into the wave's LDS tile, the next tile's loads, then the rows, last first
+    auto step = [&](int dir, int t, bool more, int dir_n, int t_n, xs_bufs<T>& cur, xs_bufs<T>& nxt) {
+        const int l0 = a + XP_TM * t;
+        const xs_row* const rw = rt + (dir * nt + t) * XP_TM;
+        if (t == nt - 1) {
+#pragma unroll
+            for (int k = 0; k < W - 1; ++k) gnext[k] = (f32x2){0.f, 0.f};         // a new sequence: no later rows yet
+        }
+        // this tile's rows were requested a whole tile ago: all of them have to be here now.  (Two sets of 37 loads in flight
+        // would also overrun the 6-bit vmcnt counter: rows consumed before they arrived in the last 16 lanes -- seen as a
+        // sporadic miscount of single rows in dw / db.)
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = xp_mfma<T>::run(cur.a[0], bfl[(n * 2) * WAVE + lane], acc);
+            acc = xp_mfma<T>::run(cur.a[1], bfl[(n * 2 + 1) * WAVE + lane], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pt[(4 * g + r) * XS_ROWP + n * 16 + ij] = acc[r];
+        }
+        issue(more ? dir_n : 0, more ? t_n : 0, more, nxt);
+#pragma unroll
+        for (int h = 1; h >= 0; --h) {
+            // ---- the gradient entering the conv, rows of this half: independent of each other ----
+            f32x2 gv[HR + W - 1];
+#pragma unroll
+            for (int k = 0; k < W - 1; ++k) gv[HR + k] = gnext[k];
+#pragma unroll
+            for (int jj = HR - 1; jj >= 0; --jj) {
+                const int j = h * HR + jj;
+                const f32x2 pv = *reinterpret_cast<const f32x2*>(&pt[j * XS_ROWP + 2 * lane]);
+                f32x2 xw[W];
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    xw[k] = xs_pair<T>::up(cur.x[j + k]);
+                    if (j + k < W - 1) xw[k] = (l0 + j + k - (W - 1) < 0) ? (f32x2){0.f, 0.f} : xw[k];  // left zero padding (first tile of the sequence)
+                }
+                f32x2 pre = bias;
+#pragma unroll
+                for (int k = 0; k < W; ++k) pre += w[k] * xw[k];
+                const f32x2 ex = pre * (-LOG2E);
+                const f32x2 den = (f32x2){fast_exp2(ex.x), fast_exp2(ex.y)} + 1.0f;
+                const f32x2 sg = {fast_rcp(den.x), fast_rcp(den.y)};
+                const f32x2 fac = sg * (1.0f + pre * (1.0f - sg));                // silu'(pre)
+                gv[jj] = (pv + xs_pair<T>::up(cur.du[j])) * fac;
+                const f32x2 gvo = gv[jj] * rw[j].own;                             // rows after the segment are someone else's
+#pragma unroll
+                for (int k = 0; k < W; ++k) dw[k] += gvo * xw[k];
+                db += gvo;
+            }
+#pragma unroll
+            for (int k = 0; k < W - 1; ++k) gnext[k] = gv[k];
+            // ---- dx[m] = sum_j w[j] * g[m + (W-1) - j], added to the token-order running sum (the rows of a direction are distinct tokens) ----
+            uint32_t* ap[HR];
+            uint32_t old[HR];
+#pragma unroll
+            for (int jj = HR - 1; jj >= 0; --jj) {
+                const int j = h * HR + jj;
+                ap[jj] = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(accs) + rw[j].acc_off) + lane;
+                old[jj] = *ap[jj];
+            }
+#pragma unroll
+            for (int jj = HR - 1; jj >= 0; --jj) {
+                f32x2 dxv = w[W - 1] * gv[jj];
+#pragma unroll
+                for (int k = 0; k < W - 1; ++k) dxv += w[W - 2 - k] * gv[jj + 1 + k];
+                const f32x2 o = xs_pair<T>::up(old[jj]) + dxv;
+                *ap[jj] = xp_mfma<T>::pack(o.x, o.y);
+            }
+        }
+        if (t == 0) __syncthreads();                                              // the next direction adds to rows other waves wrote
+    };
+
+    __syncthreads();                                                              // acc zeroed
+    xs_bufs<T> bufA, bufB;
+    issue(0, nt - 1, true, bufA);
+    int dir = 0, t = nt - 1;
+    for (int q = 0; q < nsteps; q += 2) {
+        int d1 = dir, t1 = t - 1;
+        if (t1 < 0) { d1 = dir + 1; t1 = nt - 1; }
+        step(dir, t, q + 1 < nsteps, d1, t1, bufA, bufB);
+        if (q + 1 < nsteps) {
+            int d2 = d1, t2 = t1 - 1;
+            if (t2 < 0) { d2 = d1 + 1; t2 = nt - 1; }
+            step(d1, t1, q + 2 < nsteps, d2, t2, bufB, bufA);
+            dir = d2;
+            t = t2;
+        }
+    }
+    // (the last step ended with a barrier: acc is complete, the product tiles are free)
+    {   // dx: token-order rows of the slab, 16 bytes per lane
+        const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)b * p.dx_ss + c0);
+        const int sl_dx = (int)p.dx_sl * ES;
+        const int piece = tid & 15;
+        for (int r = tid >> 4; r < L; r += XS_THREADS / 16) {
+            const xp_u32x4 v = *reinterpret_cast<const xp_u32x4*>(accs + r * AW + 4 * piece);
+            __builtin_amdgcn_raw_buffer_store_b128(v, r_dx, piece * 16, r * sl_dx, 0);
+        }
+    }
+    {   // dw | db: the 8 segments' partial sums through LDS, one row per sample (the layout of the kernel above)
+        f32x2* const red = reinterpret_cast<f32x2*>(&ptile[0][0]);               // [wave][5][64]
+#pragma unroll
+        for (int k = 0; k < W; ++k) red[(wave * (W + 1) + k) * WAVE + lane] = dw[k];
+        red[(wave * (W + 1) + W) * WAVE + lane] = db;
+        __syncthreads();
+        if (tid < (W + 1) * WAVE) {
+            const int k = tid >> 6, ln = tid & 63;
+            f32x2 sum = red[k * WAVE + ln];
+#pragma unroll
+            for (int v = 1; v < XS_NW; ++v) sum += red[(v * (W + 1) + k) * WAVE + ln];
+            const int ch = c0 + 2 * ln;
+            const int64_t row = (int64_t)b * (p.part_ss ? p.part_ss : (int64_t)p.dim * W);
+            if (k < W) {
+                p.dw_partial[row + (int64_t)ch * W + k] = sum.x;
+                p.dw_partial[row + (int64_t)(ch + 1) * W + k] = sum.y;
+            } else if (p.db_partial) {
+                const int64_t rb = (int64_t)b * (p.part_ss ? p.part_ss : (int64_t)p.dim);
+                p.db_partial[rb + ch] = sum.x;
+                p.db_partial[rb + ch + 1] = sum.y;
+            }
+        }
+    }
+}
+
+// DM_K4X_SLAB=0 never, =1 whenever it is legal, unset: sequences of 32 .. 256 rows
+static bool xs_use_slab(const dm_conv_xproj_bwd_args& a) {
+    if (a.seqlen > XS_MAXL || a.dim % XS_CS || a.ndir > XS_MAXDIR) return false;
+    if (((uintptr_t)a.dx & 15) || (a.dx_ss & 7) || (a.dx_sl & 7)) return false;   // 16-byte dx pieces
+    const char* e = getenv("DM_K4X_SLAB");
+    if (e && *e) return *e != '0';
+    return a.seqlen >= 32;
+}
+
 template <typename T, typename TW, int W, int D>
 static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
     dim3 grid(a.ndir * a.batch), block(XP_THREADS);
     const bool silu = (a.flags & DM_FLAG_SILU) != 0;
     if constexpr (W == 4) {                                          // the merged form is built for the mixer's call pattern
         if ((a.flags & DM_FLAG_DX_MERGED) && silu && a.row_index) {
+            if (xs_use_slab(a)) {
+                hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW>), dim3(a.batch * (a.dim / XS_CS)), dim3(XS_THREADS), 0, st, a);
+                return;
+            }
             hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, true, true>), dim3(a.batch), block, 0, st, a);
             return;
         }

@@ -961,13 +961,21 @@ def test_spiral_ssm_hoisted_equals_in_scan_gate(gpu, dtype, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("Bsz,L,Dm,ndir", [(2, 196, 1024, 3), (3, 49, 128, 3), (2, 5, 1024, 2), (1, 37, 128, 4)])
-def test_fused_conv_xproj_bwd_merged_directions(gpu, dtype, Bsz, L, Dm, ndir):
-    """K4x with DM_FLAG_DX_MERGED: one workgroup per sample walks the directions, dx accumulates in ONE token-order buffer (a strided
-    view: the x half of d(xz)); against fp64 autograd (the gradient of x summed over the directions), against the slab form +
-    dm_token_merge, and dw / db from one partial row per sample.  The neighbouring z half must stay untouched."""
+@pytest.mark.parametrize("slab", ["0", "1"])
+@pytest.mark.parametrize("Bsz,L,Dm,ndir", [(2, 196, 1024, 3), (3, 49, 128, 3), (2, 5, 1024, 2), (1, 37, 128, 4), (8, 256, 256, 3),
+                                           (16, 100, 128, 1)])
+def test_fused_conv_xproj_bwd_merged_directions(gpu, monkeypatch, dtype, slab, Bsz, L, Dm, ndir):
+    """K4x with DM_FLAG_DX_MERGED, both forms -- the whole-sample form (slab 0: one workgroup per sample walks the directions, dx
+    accumulates in ONE token-order buffer in HBM) and the slab form (slab 1, sequences up to 256 rows: a workgroup per (sample,
+    128 channels), the running sum in LDS, the gathered sequence cut into 8 segments) -- against fp64 autograd (the gradient of x
+    summed over the directions), against the per-direction slabs + dm_token_merge, and dw / db from one partial row per sample.  dx
+    is a strided view (the x half of d(xz)): the neighbouring z half must stay untouched.  Sequence lengths: the model's 196, one
+    with idle waves (5 rows for 8 segments), odd ones, the largest the slab form takes, a batch of 8 (its XCD-aware workgroup
+    order)."""
     from diffma_amd import hip_ops
     from oracle.mamba_ref import causal_conv1d_ref
+
+    monkeypatch.setenv("DM_K4X_SLAB", slab)
 
     P, W = 64, 4
     g = torch.Generator().manual_seed(L * 7 + Dm + ndir)
