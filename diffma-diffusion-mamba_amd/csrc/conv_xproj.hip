@@ -518,7 +518,7 @@ constexpr int XS_THREADS = XS_NW * WAVE;
 constexpr int XS_MAXL = 256;               // acc rows (+ 1 dummy row that takes the stores of rows a wave does not own)
 constexpr int XS_ROWP = XS_CS + 4;         // fp32 product tile row stride (rows 4g + r of a D-fragment on disjoint banks)
 constexpr int XS_MAXDIR = 4;
-constexpr int XS_SLOTS = ((XS_MAXL / XS_NW + 3 + XP_TM - 1) / XP_TM) * XP_TM;     // rows a wave walks per direction (whole tiles)
+constexpr int XS_SLOTS = ((XS_MAXL / XS_NW + 3 + XP_TM - 1) / XP_TM) * XP_TM;     // rows a wave walks per direction (whole tiles: 48 = 3 x 16 >= 3 x 14)
 // Per (direction, row slot) of a wave.  `own` comes FIRST: it multiplies a float2 as a broadcast of the LOW dword of the pair the
 // table read returns (op_sel_hi).  With acc_off first the compiler broadcasts the HIGH dword (op_sel:[1,0], or a v_mov into the low
 // register right in front of the v_pk_mul), and on MI355X that form gave the last 16 lanes a stale value for their first channel
@@ -539,15 +539,18 @@ __device__ __forceinline__ int64_t xs_uniform64(int64_t v) {      // a wave-unif
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <typename T> struct xs_bufs {     // one tile's prefetched rows
-    uint32_t x[XP_TM + 3];                 // x rows l0-3 .. l0+15 (gathered), the lane's channel pair
-    uint32_t du[XP_TM];
+template <typename T, int RT> struct xs_bufs {     // one tile's prefetched rows
+    uint32_t x[RT + 3];                    // x rows l0-3 .. l0+RT-1 (gathered), the lane's channel pair
+    uint32_t du[RT];
     xp_u32x4 a[2];                         // d x_dbl rows l0 .. l0+15 as MFMA A-fragments
 };
 
-template <typename T, typename TW>
+// RT: rows of a tile the conv walks (the product tile always has the 16 rows of the MFMA): 16, or 14 when that wastes fewer row
+// slots -- at L = 196 a wave walks 25 + 3 rows per direction = 2 x 14.
+template <typename T, typename TW, int RT>
 __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(const dm_conv_xproj_bwd_args p) {
-    constexpr int W = 4, KP = 64, NT = XS_CS / 16, ES = (int)sizeof(T), NXR = XP_TM + W - 1, AW = XS_CS / 2, HR = XP_TM / 2;
+    constexpr int W = 4, KP = 64, NT = XS_CS / 16, ES = (int)sizeof(T), NXR = RT + W - 1, AW = XS_CS / 2, HR = RT / 2;
+    static_assert(RT % 2 == 0 && RT <= XP_TM, "whole half tiles");
     __shared__ __attribute__((aligned(16))) uint32_t accs[(XS_MAXL + 1) * AW];
     __shared__ __attribute__((aligned(16))) float ptile[XS_NW][XP_TM * XS_ROWP];
     __shared__ __attribute__((aligned(16))) xp_u32x4 bfl[NT * 2 * WAVE];          // x_proj.weight^T of the slab in MFMA B-fragment order
@@ -598,14 +601,14 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     const int seg = (L + XS_NW - 1) / XS_NW;
     const int a = wave * seg;
     const int e = (a + seg < L) ? a + seg : L;
-    const int nt = (seg + (W - 1) + XP_TM - 1) / XP_TM;
+    const int nt = (seg + (W - 1) + RT - 1) / RT;
     const int nsteps = p.ndir * nt;
     float* const pt = ptile[wave];
     // where the dx of (direction, row slot) goes and whether the row counts for dw / db: this wave's rows add to their token's row of
     // acc, the rows it only recomputes (the 3 after its segment, the rest of the tile) store to a dummy row
     xs_row* const rt = rowtab[wave];
-    for (int q = lane; q < p.ndir * nt * XP_TM; q += WAVE) {
-        const int dir = q / (nt * XP_TM), l = a + q % (nt * XP_TM);
+    for (int q = lane; q < p.ndir * nt * RT; q += WAVE) {
+        const int dir = q / (nt * RT), l = a + q % (nt * RT);
         const bool own = l < e;
         rt[q].acc_off = (uint32_t)((own ? p.row_index[dir * L + l] : XS_MAXL) * AW * 4);
         rt[q].own = own ? 1.0f : 0.0f;
@@ -622,8 +625,8 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     // `live` false (after the last tile): the same instructions with an out-of-range lane offset -- they load nothing, and the
     // number of loads in flight stays what the compiler's s_waitcnt bookkeeping assumes on every path (a branch around the loads
     // makes it wait for the NEW loads wherever it has to wait for an old one: no prefetch left)
-    auto issue = [&](int dir, int t, bool live, xs_bufs<T>& o) {
-        const int l0 = a + XP_TM * t;
+    auto issue = [&](int dir, int t, bool live, xs_bufs<T, RT>& o) {
+        const int l0 = a + RT * t;
         const int vo_l = live ? vo : BIO_OOB;
         const T* dup = du0;
         const T* xdp = xd0;
@@ -642,12 +645,12 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
             o.x[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo_l, idx[lr < 0 ? 0 : (lr < L ? lr : L - 1)] * sl_x, 0);
         }
 #pragma unroll
-        for (int j = XP_TM - 1; j >= 0; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
+        for (int j = RT - 1; j >= 0; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
     };
     // one tile: product on the matrix pipe into the wave's LDS tile, the next tile's loads, then the rows, last first
-    auto step = [&](int dir, int t, bool more, int dir_n, int t_n, xs_bufs<T>& cur, xs_bufs<T>& nxt) {
-        const int l0 = a + XP_TM * t;
-        const xs_row* const rw = rt + (dir * nt + t) * XP_TM;
+    auto step = [&](int dir, int t, bool more, int dir_n, int t_n, xs_bufs<T, RT>& cur, xs_bufs<T, RT>& nxt) {
+        const int l0 = a + RT * t;
+        const xs_row* const rw = rt + (dir * nt + t) * RT;
         if (t == nt - 1) {
 #pragma unroll
             for (int k = 0; k < W - 1; ++k) gnext[k] = (f32x2){0.f, 0.f};         // a new sequence: no later rows yet
@@ -718,7 +721,7 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     };
 
     __syncthreads();                                                              // acc zeroed
-    xs_bufs<T> bufA, bufB;
+    xs_bufs<T, RT> bufA, bufB;
     issue(0, nt - 1, true, bufA);
     int dir = 0, t = nt - 1;
     for (int q = 0; q < nsteps; q += 2) {
@@ -784,7 +787,10 @@ static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
     if constexpr (W == 4) {                                          // the merged form is built for the mixer's call pattern
         if ((a.flags & DM_FLAG_DX_MERGED) && silu && a.row_index) {
             if (xs_use_slab(a)) {
-                hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW>), dim3(a.batch * (a.dim / XS_CS)), dim3(XS_THREADS), 0, st, a);
+                const int rows = (a.seqlen + XS_NW - 1) / XS_NW + 3;                 // a wave's rows per direction
+                const dim3 g(a.batch * (a.dim / XS_CS)), blk(XS_THREADS);
+                if (14 * ((rows + 13) / 14) < 16 * ((rows + 15) / 16)) hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 14>), g, blk, 0, st, a);
+                else hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 16>), g, blk, 0, st, a);
                 return;
             }
             hipLaunchKernelGGL((conv_xproj_bwd_kernel<T, TW, W, true, D, true, true>), dim3(a.batch), block, 0, st, a);

@@ -14,6 +14,6 @@ cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels order by total_duration desc limit 40"))
 with open("$R/gpurun_out/${TAG}_top.txt", "w") as f:
     for n, c, t, a, p in rows:
-        f.write(f"{p:6.2f}% calls={c:6d} avg_us={a/1e3:10.1f} tot_ms={t/1e6:10.2f} (raw avg {a})  {n[:120]}\n")
+        f.write(f"{p:6.2f}% calls={c:6d} avg_us={a:10.1f} tot_ms={t/1e3:10.2f}  {n[:120]}\n")
 print(open("$R/gpurun_out/${TAG}_top.txt").read())
 PY
