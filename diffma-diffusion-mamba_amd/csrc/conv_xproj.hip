@@ -524,6 +524,7 @@ constexpr int XS_SLOTS = ((XS_MAXL / XS_NW + 3 + XP_TM - 1) / XP_TM) * XP_TM;   
 // register right in front of the v_pk_mul), and on MI355X that form gave the last 16 lanes a stale value for their first channel
 // now and then -- single rows missing from dw / db in a few channels (tools/dbg_k4x2.py; ROCm 7.2 hipcc).
 struct xs_row { float own; uint32_t acc_off; };
+constexpr int XS_TOKP = XS_MAXL + 32;        // tokens of rows -3 .. L-1+, padded: a tile may start 3 rows early and end past the sequence
 
 template <typename T> struct xs_pair;      // the lane's two 16-bit channels <-> float2
 template <> struct xs_pair<bf16_t> {
@@ -547,6 +548,15 @@ template <typename T, int RT> struct xs_bufs {     // one tile's prefetched rows
 
 // RT: rows of a tile the conv walks (the product tile always has the 16 rows of the MFMA): 16, or 14 when that wastes fewer row
 // slots -- at L = 196 a wave walks 25 + 3 rows per direction = 2 x 14.
+//
+// PERSISTENT: the grid is one workgroup per CU (LDS allows no second one), and a workgroup keeps its SLAB while it walks through
+// samples: x_proj.weight^T fragments, conv weights, the row tables are set up once, and the first tile of the next sample is
+// requested during the last tile of the current one -- with one workgroup per CU nothing else would cover a workgroup's start-up
+// (weights, tables, the first loads' latency) and its dx write-out.  Workgroup k: XCD k % 8, slab (k / 8) % nslab, sample stream
+// (k / 8) / nslab; its samples are b = (it * nstream + stream) * 8 + xcd: the slabs of one sample run at the same time on ONE XCD, so
+// the sample's d x_dbl rows (read by every slab) are fetched into one L2 and the 256-byte pieces of a du row are requested together.
+// dw / db: summed over the workgroup's samples in registers, written once into the partial row of its first sample (zeros into the
+// rows of the others: the caller sums the rows).
 template <typename T, typename TW, int RT>
 __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(const dm_conv_xproj_bwd_args p) {
     constexpr int W = 4, KP = 64, NT = XS_CS / 16, ES = (int)sizeof(T), NXR = RT + W - 1, AW = XS_CS / 2, HR = RT / 2;
@@ -555,26 +565,25 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     __shared__ __attribute__((aligned(16))) float ptile[XS_NW][XP_TM * XS_ROWP];
     __shared__ __attribute__((aligned(16))) xp_u32x4 bfl[NT * 2 * WAVE];          // x_proj.weight^T of the slab in MFMA B-fragment order
     __shared__ __attribute__((aligned(8))) xs_row rowtab[XS_NW][XS_MAXDIR * XS_SLOTS];
+    __shared__ uint8_t xtok[XS_MAXDIR][XS_TOKP];                                  // token of gathered row l at [dir][l + 3], l = -3 .. (clamped into the sequence)
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = lane >> 4, ij = lane & 15;
     const int L = p.seqlen, nslab = p.dim / XS_CS;
-    // workgroup -> (sample, slab): workgroups are dealt to the 8 XCDs round-robin; the slabs of one sample go to ONE XCD, so its
-    // d x_dbl rows (read by every slab) and the row tables are fetched into one L2, and the 8 x 256-byte pieces of a du row are
-    // requested close together in time
-    int b, slab;
-    {
-        const int i = (int)blockIdx.x;
-        if ((p.batch & 7) == 0) { const int q = i >> 3; slab = q % nslab; b = (q / nslab) * 8 + (i & 7); }
-        else { b = i / nslab; slab = i % nslab; }
-    }
+    const int xcd = (int)blockIdx.x & 7, kq = (int)blockIdx.x >> 3;
+    const int slab = kq % nslab, nstream = ((int)gridDim.x >> 3) / nslab, bstep = 8 * nstream;
+    const int b_first = (kq / nslab) * 8 + xcd;
+    if (b_first >= p.batch) return;                                               // (workgroup-uniform: before any barrier)
     const int c0 = slab * XS_CS, c = c0 + 2 * lane;
     {   // the running sum starts at zero: direction 0 adds like the others
         const xp_u32x4 z = {0u, 0u, 0u, 0u};
         for (int q = tid; q < L * (AW / 4); q += XS_THREADS) reinterpret_cast<xp_u32x4*>(accs)[q] = z;
     }
-    const rsrc_t r_x = make_rsrc_2g((const T*)p.x + (int64_t)b * p.x_sb + c0);      // (bounded: an offset of BIO_OOB loads nothing)
+    for (int q = tid; q < p.ndir * XS_TOKP; q += XS_THREADS) {
+        const int dir = q / XS_TOKP, lr = q % XS_TOKP - (W - 1);
+        xtok[dir][q % XS_TOKP] = (uint8_t)p.row_index[dir * L + (lr < 0 ? 0 : (lr < L ? lr : L - 1))];
+    }
     const rsrc_t r_wt = make_rsrc((const T*)p.wxt + (int64_t)c0 * KP);
     const int vo = 2 * lane * ES;
     const int sl_x = (int)p.x_sl * ES, sl_du = (int)p.du_sl * ES, sr_xd = (int)p.xd_sr * ES;
@@ -597,12 +606,11 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     db = (f32x2){0.f, 0.f};
 
     // this wave's segment [a, e) of every gathered sequence; every wave runs the same number of tiles (a wave whose segment lies
-    // past the end works on masked rows: only sequences shorter than 8 x 13 rows have such waves)
+    // past the end works on masked rows: only short sequences have such waves)
     const int seg = (L + XS_NW - 1) / XS_NW;
     const int a = wave * seg;
     const int e = (a + seg < L) ? a + seg : L;
     const int nt = (seg + (W - 1) + RT - 1) / RT;
-    const int nsteps = p.ndir * nt;
     float* const pt = ptile[wave];
     // where the dx of (direction, row slot) goes and whether the row counts for dw / db: this wave's rows add to their token's row of
     // acc, the rows it only recomputes (the 3 after its segment, the rest of the tile) store to a dummy row
@@ -616,48 +624,40 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     const int du_bytes = (L - 1) * sl_du + XS_CS * ES;   // a du / d x_dbl row past the end of the sequence is out of the descriptor's range:
     const int xd_bytes = L * sr_xd;                       // it loads as ZERO, and with it the gradient of the row
 
-    // loads of step (dir, t): rows l0 = a + 16 t ..
-    // per-direction bases advance by ADDITION (a 64-bit multiply by the direction is moved to the vector unit by the compiler, and
-    // every address derived from it then needs a waterfall loop)
-    const int64_t du_step = xs_uniform64((int64_t)p.batch * p.du_ss), xd_step = xs_uniform64((int64_t)p.batch * L * p.xd_sr);
-    const T* const du0 = (const T*)p.du + xs_uniform64((int64_t)b * p.du_ss + c0);
-    const T* const xd0 = (const T*)p.dxdbl + xs_uniform64((int64_t)b * L * p.xd_sr);
-    // `live` false (after the last tile): the same instructions with an out-of-range lane offset -- they load nothing, and the
-    // number of loads in flight stays what the compiler's s_waitcnt bookkeeping assumes on every path (a branch around the loads
-    // makes it wait for the NEW loads wherever it has to wait for an old one: no prefetch left)
-    auto issue = [&](int dir, int t, bool live, xs_bufs<T, RT>& o) {
+    // Loads of tile (sample bb, direction dir, tile t): rows l0 = a + RT t ...  `live` false (after the last tile): the same
+    // instructions with an out-of-range lane offset -- they load nothing, and the number of loads in flight stays what the compiler's
+    // s_waitcnt bookkeeping assumes on every path (a branch around the loads makes it wait for the NEW loads wherever it has to wait
+    // for an old one: no prefetch left).  Bases: 64-bit products are formed on the vector unit by this compiler; xs_uniform64 brings
+    // them back to SGPRs (an address left in VGPRs costs a waterfall loop per load).
+    auto issue = [&](int bb, int dir, int t, bool live, xs_bufs<T, RT>& o) {
         const int l0 = a + RT * t;
         const int vo_l = live ? vo : BIO_OOB;
-        const T* dup = du0;
-        const T* xdp = xd0;
-        for (int k = 0; k < dir; ++k) { dup += du_step; xdp += xd_step; }
-        const cptr<int32_t> idx = as_const(p.row_index + dir * L);
-        const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dup), 0, du_bytes, 0x00020000);
-        const rsrc_t r_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xdp), 0, xd_bytes, 0x00020000);
+        const int s = dir * p.batch + bb;
+        const rsrc_t r_x = make_rsrc_2g((const T*)p.x + xs_uniform64((int64_t)bb * p.x_sb + c0));
+        const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.du + xs_uniform64((int64_t)s * p.du_ss + c0)), 0, du_bytes, 0x00020000);
+        const rsrc_t r_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.dxdbl + xs_uniform64((int64_t)s * L * p.xd_sr)), 0, xd_bytes, 0x00020000);
+        // the tokens of the tile's x rows: one LDS byte per lane, handed to the scalar unit lane by lane
+        const int tokv = xtok[dir][l0 + (lane < NXR ? lane : NXR - 1)];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, live ? (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES : BIO_OOB, 0, 0);
             o.a[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
         }
 #pragma unroll
-        for (int j = NXR - 1; j >= 0; --j) {
-            const int lr = l0 - (W - 1) + j;
-            o.x[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo_l, idx[lr < 0 ? 0 : (lr < L ? lr : L - 1)] * sl_x, 0);
-        }
+        for (int j = NXR - 1; j >= 0; --j) o.x[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo_l, __builtin_amdgcn_readlane(tokv, j) * sl_x, 0);
 #pragma unroll
         for (int j = RT - 1; j >= 0; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
     };
     // one tile: product on the matrix pipe into the wave's LDS tile, the next tile's loads, then the rows, last first
-    auto step = [&](int dir, int t, bool more, int dir_n, int t_n, xs_bufs<T, RT>& cur, xs_bufs<T, RT>& nxt) {
+    auto step = [&](int bb, int dir, int t, bool more, int b_n, int dir_n, int t_n, xs_bufs<T, RT>& cur, xs_bufs<T, RT>& nxt) {
         const int l0 = a + RT * t;
         const xs_row* const rw = rt + (dir * nt + t) * RT;
         if (t == nt - 1) {
 #pragma unroll
             for (int k = 0; k < W - 1; ++k) gnext[k] = (f32x2){0.f, 0.f};         // a new sequence: no later rows yet
         }
-        // this tile's rows were requested a whole tile ago: all of them have to be here now.  (Two sets of 37 loads in flight
-        // would also overrun the 6-bit vmcnt counter: rows consumed before they arrived in the last 16 lanes -- seen as a
-        // sporadic miscount of single rows in dw / db.)
+        // this tile's rows were requested a whole tile ago: all of them have to be here now (and two sets of 35 loads in flight
+        // would overrun the 6-bit vmcnt counter)
         __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) pt[(4 * g + r) * XS_ROWP + n * 16 + ij] = acc[r];
         }
-        issue(more ? dir_n : 0, more ? t_n : 0, more, nxt);
+        issue(more ? b_n : bb, more ? dir_n : 0, more ? t_n : 0, more, nxt);
 #pragma unroll
         for (int h = 1; h >= 0; --h) {
             // ---- the gradient entering the conv, rows of this half: independent of each other ----
@@ -717,36 +717,44 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
                 *ap[jj] = xp_mfma<T>::pack(o.x, o.y);
             }
         }
-        if (t == 0) __syncthreads();                                              // the next direction adds to rows other waves wrote
+        if (t == 0) {
+            __syncthreads();                                                      // the next direction adds to rows other waves wrote
+            if (dir == p.ndir - 1) {                                              // the sample is complete: dx leaves as 16-byte pieces, acc starts over
+                const rsrc_t r_dx = make_rsrc((T*)p.dx + xs_uniform64((int64_t)bb * p.dx_ss + c0));
+                const int sl_dx = (int)p.dx_sl * ES;
+                const int piece = tid & 15;
+                const xp_u32x4 z = {0u, 0u, 0u, 0u};
+                for (int r = tid >> 4; r < L; r += XS_THREADS / 16) {
+                    xp_u32x4* const q = reinterpret_cast<xp_u32x4*>(accs + r * AW + 4 * piece);
+                    __builtin_amdgcn_raw_buffer_store_b128(*q, r_dx, piece * 16 + r * sl_dx, 0, 0);      // (the row differs inside a wave: lane offset)
+                    *q = z;
+                }
+                __syncthreads();
+            }
+        }
     };
 
-    __syncthreads();                                                              // acc zeroed
+    __syncthreads();                                                              // acc zeroed, tables and fragments in place
     xs_bufs<T, RT> bufA, bufB;
-    issue(0, nt - 1, true, bufA);
-    int dir = 0, t = nt - 1;
-    for (int q = 0; q < nsteps; q += 2) {
-        int d1 = dir, t1 = t - 1;
-        if (t1 < 0) { d1 = dir + 1; t1 = nt - 1; }
-        step(dir, t, q + 1 < nsteps, d1, t1, bufA, bufB);
-        if (q + 1 < nsteps) {
-            int d2 = d1, t2 = t1 - 1;
-            if (t2 < 0) { d2 = d1 + 1; t2 = nt - 1; }
-            step(d1, t1, q + 2 < nsteps, d2, t2, bufB, bufA);
-            dir = d2;
-            t = t2;
-        }
+    issue(b_first, 0, nt - 1, true, bufA);
+    // the tile after (bb, dir, t)
+    auto after = [&](int bb, int dir, int t, int& b2, int& d2, int& t2) {
+        b2 = bb; d2 = dir; t2 = t - 1;
+        if (t2 < 0) { t2 = nt - 1; d2 = dir + 1; }
+        if (d2 == p.ndir) { d2 = 0; b2 = bb + bstep; }
+    };
+    int bb = b_first, dir = 0, t = nt - 1;
+    while (bb < p.batch) {
+        int b1, d1, t1, b2, d2, t2;
+        after(bb, dir, t, b1, d1, t1);
+        step(bb, dir, t, b1 < p.batch, b1, d1, t1, bufA, bufB);
+        if (b1 >= p.batch) break;
+        after(b1, d1, t1, b2, d2, t2);
+        step(b1, d1, t1, b2 < p.batch, b2, d2, t2, bufB, bufA);
+        bb = b2; dir = d2; t = t2;
     }
-    // (the last step ended with a barrier: acc is complete, the product tiles are free)
-    {   // dx: token-order rows of the slab, 16 bytes per lane
-        const rsrc_t r_dx = make_rsrc((T*)p.dx + (int64_t)b * p.dx_ss + c0);
-        const int sl_dx = (int)p.dx_sl * ES;
-        const int piece = tid & 15;
-        for (int r = tid >> 4; r < L; r += XS_THREADS / 16) {
-            const xp_u32x4 v = *reinterpret_cast<const xp_u32x4*>(accs + r * AW + 4 * piece);
-            __builtin_amdgcn_raw_buffer_store_b128(v, r_dx, piece * 16, r * sl_dx, 0);
-        }
-    }
-    {   // dw | db: the 8 segments' partial sums through LDS, one row per sample (the layout of the kernel above)
+    {   // dw | db: the 8 segments' sums through LDS (the product tiles are free), into the partial row of the first sample; zeros into
+        // the rows of the workgroup's other samples (the layout of the kernel above: one row per sample)
         f32x2* const red = reinterpret_cast<f32x2*>(&ptile[0][0]);               // [wave][5][64]
 #pragma unroll
         for (int k = 0; k < W; ++k) red[(wave * (W + 1) + k) * WAVE + lane] = dw[k];
@@ -758,17 +766,30 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 #pragma unroll
             for (int v = 1; v < XS_NW; ++v) sum += red[(v * (W + 1) + k) * WAVE + ln];
             const int ch = c0 + 2 * ln;
-            const int64_t row = (int64_t)b * (p.part_ss ? p.part_ss : (int64_t)p.dim * W);
-            if (k < W) {
-                p.dw_partial[row + (int64_t)ch * W + k] = sum.x;
-                p.dw_partial[row + (int64_t)(ch + 1) * W + k] = sum.y;
-            } else if (p.db_partial) {
-                const int64_t rb = (int64_t)b * (p.part_ss ? p.part_ss : (int64_t)p.dim);
-                p.db_partial[rb + ch] = sum.x;
-                p.db_partial[rb + ch + 1] = sum.y;
+            for (int b2 = b_first; b2 < p.batch; b2 += bstep) {
+                if (k < W) {
+                    const int64_t row = (int64_t)b2 * (p.part_ss ? p.part_ss : (int64_t)p.dim * W);
+                    p.dw_partial[row + (int64_t)ch * W + k] = sum.x;
+                    p.dw_partial[row + (int64_t)(ch + 1) * W + k] = sum.y;
+                } else if (p.db_partial) {
+                    const int64_t rb = (int64_t)b2 * (p.part_ss ? p.part_ss : (int64_t)p.dim);
+                    p.db_partial[rb + ch] = sum.x;
+                    p.db_partial[rb + ch + 1] = sum.y;
+                }
+                sum = (f32x2){0.f, 0.f};
             }
         }
     }
+}
+
+static int xs_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
 }
 
 // DM_K4X_SLAB=0 never, =1 whenever it is legal, unset: sequences of 32 .. 256 rows
@@ -788,7 +809,12 @@ static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
         if ((a.flags & DM_FLAG_DX_MERGED) && silu && a.row_index) {
             if (xs_use_slab(a)) {
                 const int rows = (a.seqlen + XS_NW - 1) / XS_NW + 3;                 // a wave's rows per direction
-                const dim3 g(a.batch * (a.dim / XS_CS)), blk(XS_THREADS);
+                // one workgroup per CU, in units of (8 XCDs x the slabs of a sample); fewer when the batch is small
+                const int nslab = a.dim / XS_CS;
+                int nstream = xs_cu_count() / 8 / nslab;
+                if (nstream < 1) nstream = 1;
+                if (nstream > (a.batch + 7) / 8) nstream = (a.batch + 7) / 8;
+                const dim3 g(8 * nslab * nstream), blk(XS_THREADS);
                 if (14 * ((rows + 13) / 14) < 16 * ((rows + 15) / 16)) hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 14>), g, blk, 0, st, a);
                 else hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 16>), g, blk, 0, st, a);
                 return;
