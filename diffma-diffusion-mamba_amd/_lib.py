@@ -28,6 +28,7 @@ DM_FLAG_SCAN_CHUNKED = 32
 DM_FLAG_OUT_ACCUMULATE = 64
 DM_FLAG_DELTA_ACTIVATED = 128
 DM_FLAG_DX_MERGED = 256
+DM_FLAG_PARTIAL_COMPACT = 512
 
 _SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
 

@@ -624,20 +624,20 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     const int du_bytes = (L - 1) * sl_du + XS_CS * ES;   // a du / d x_dbl row past the end of the sequence is out of the descriptor's range:
     const int xd_bytes = L * sr_xd;                       // it loads as ZERO, and with it the gradient of the row
 
-    // Loads of tile (sample bb, direction dir, tile t): rows l0 = a + RT t ...  `live` false (after the last tile): the same
+    // Loads of tile (sample bb, direction dir, tile t): rows l0 = a + RT t ...  tokv: the tokens of the tile's x rows, one LDS byte per
+    // lane (`tokens`, read ahead of time), handed to the scalar unit lane by lane.  `live` false (after the last tile): the same
     // instructions with an out-of-range lane offset -- they load nothing, and the number of loads in flight stays what the compiler's
     // s_waitcnt bookkeeping assumes on every path (a branch around the loads makes it wait for the NEW loads wherever it has to wait
     // for an old one: no prefetch left).  Bases: 64-bit products are formed on the vector unit by this compiler; xs_uniform64 brings
     // them back to SGPRs (an address left in VGPRs costs a waterfall loop per load).
-    auto issue = [&](int bb, int dir, int t, bool live, xs_bufs<T, RT>& o) {
+    auto tokens = [&](int dir, int t) -> int { return xtok[dir][a + RT * t + (lane < NXR ? lane : NXR - 1)]; };
+    auto issue = [&](int bb, int dir, int t, bool live, int tokv, xs_bufs<T, RT>& o) {
         const int l0 = a + RT * t;
         const int vo_l = live ? vo : BIO_OOB;
         const int s = dir * p.batch + bb;
         const rsrc_t r_x = make_rsrc_2g((const T*)p.x + xs_uniform64((int64_t)bb * p.x_sb + c0));
         const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.du + xs_uniform64((int64_t)s * p.du_ss + c0)), 0, du_bytes, 0x00020000);
         const rsrc_t r_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.dxdbl + xs_uniform64((int64_t)s * L * p.xd_sr)), 0, xd_bytes, 0x00020000);
-        // the tokens of the tile's x rows: one LDS byte per lane, handed to the scalar unit lane by lane
-        const int tokv = xtok[dir][l0 + (lane < NXR ? lane : NXR - 1)];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, live ? (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES : BIO_OOB, 0, 0);
@@ -656,9 +656,11 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 #pragma unroll
             for (int k = 0; k < W - 1; ++k) gnext[k] = (f32x2){0.f, 0.f};         // a new sequence: no later rows yet
         }
+        const int tok_n = tokens(more ? dir_n : 0, more ? t_n : 0);
         // this tile's rows were requested a whole tile ago: all of them have to be here now (and two sets of 35 loads in flight
-        // would overrun the 6-bit vmcnt counter)
+        // would overrun the 6-bit vmcnt counter); the next tile's go out at once, ahead of the product
         __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
+        issue(more ? b_n : bb, more ? dir_n : 0, more ? t_n : 0, more, tok_n, nxt);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -667,7 +669,6 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) pt[(4 * g + r) * XS_ROWP + n * 16 + ij] = acc[r];
         }
-        issue(more ? b_n : bb, more ? dir_n : 0, more ? t_n : 0, more, nxt);
 #pragma unroll
         for (int h = 1; h >= 0; --h) {
             // ---- the gradient entering the conv, rows of this half: independent of each other ----
@@ -736,7 +737,7 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 
     __syncthreads();                                                              // acc zeroed, tables and fragments in place
     xs_bufs<T, RT> bufA, bufB;
-    issue(b_first, 0, nt - 1, true, bufA);
+    issue(b_first, 0, nt - 1, true, tokens(0, nt - 1), bufA);
     // the tile after (bb, dir, t)
     auto after = [&](int bb, int dir, int t, int& b2, int& d2, int& t2) {
         b2 = bb; d2 = dir; t2 = t - 1;
@@ -766,7 +767,8 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 #pragma unroll
             for (int v = 1; v < XS_NW; ++v) sum += red[(v * (W + 1) + k) * WAVE + ln];
             const int ch = c0 + 2 * ln;
-            for (int b2 = b_first; b2 < p.batch; b2 += bstep) {
+            const int b_end = (p.flags & DM_FLAG_PARTIAL_COMPACT) ? b_first + 1 : p.batch;      // compact: the caller sums the first rows only
+            for (int b2 = b_first; b2 < b_end; b2 += bstep) {
                 if (k < W) {
                     const int64_t row = (int64_t)b2 * (p.part_ss ? p.part_ss : (int64_t)p.dim * W);
                     p.dw_partial[row + (int64_t)ch * W + k] = sum.x;
@@ -792,6 +794,14 @@ static int xs_cu_count() {
     return n;
 }
 
+// one workgroup per CU, in units of (8 XCDs x the slabs of a sample); fewer when the batch is small
+static int xs_streams(const dm_conv_xproj_bwd_args& a) {
+    int nstream = xs_cu_count() / 8 / (a.dim / XS_CS);
+    if (nstream < 1) nstream = 1;
+    if (nstream > (a.batch + 7) / 8) nstream = (a.batch + 7) / 8;
+    return nstream;
+}
+
 // DM_K4X_SLAB=0 never, =1 whenever it is legal, unset: sequences of 32 .. 256 rows
 static bool xs_use_slab(const dm_conv_xproj_bwd_args& a) {
     if (a.seqlen > XS_MAXL || a.dim % XS_CS || a.ndir > XS_MAXDIR) return false;
@@ -809,11 +819,7 @@ static void launch_xpb(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
         if ((a.flags & DM_FLAG_DX_MERGED) && silu && a.row_index) {
             if (xs_use_slab(a)) {
                 const int rows = (a.seqlen + XS_NW - 1) / XS_NW + 3;                 // a wave's rows per direction
-                // one workgroup per CU, in units of (8 XCDs x the slabs of a sample); fewer when the batch is small
-                const int nslab = a.dim / XS_CS;
-                int nstream = xs_cu_count() / 8 / nslab;
-                if (nstream < 1) nstream = 1;
-                if (nstream > (a.batch + 7) / 8) nstream = (a.batch + 7) / 8;
+                const int nslab = a.dim / XS_CS, nstream = xs_streams(a);
                 const dim3 g(8 * nslab * nstream), blk(XS_THREADS);
                 if (14 * ((rows + 13) / 14) < 16 * ((rows + 15) / 16)) hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 14>), g, blk, 0, st, a);
                 else hipLaunchKernelGGL((conv_xproj_bwd_slab_kernel<T, TW, 16>), g, blk, 0, st, a);
@@ -865,6 +871,14 @@ static int xpb_by_width(const dm_conv_xproj_bwd_args& a, hipStream_t st) {
 extern "C" int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype) {
     const bool d_ok = dim == 128 || dim == 256 || dim == 512 || dim == 1024;
     return (d_ok && nproj == 64 && (io_dtype == DM_BF16 || io_dtype == DM_F16)) ? 1 : 0;      // DiffMa: dt_rank 32 + 2 * d_state 16
+}
+
+extern "C" int dm_gather_conv1d_xproj_bwd_slab(const dm_conv_xproj_bwd_args* args, void*) {
+    if (!args) return 0;
+    const dm_conv_xproj_bwd_args& a = *args;
+    if (!((a.flags & DM_FLAG_DX_MERGED) && (a.flags & DM_FLAG_SILU) && a.row_index && a.width == 4 && dm::xs_use_slab(a))) return 0;
+    const int rows = 8 * dm::xs_streams(a);
+    return rows < a.batch ? rows : a.batch;
 }
 
 extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, void* stream) {

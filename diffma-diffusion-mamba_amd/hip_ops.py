@@ -6,12 +6,13 @@ reference-facing operator names live in selective_scan_interface.py.
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import torch
 
 from . import _lib
-from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
+from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_PARTIAL_COMPACT, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
                    dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
@@ -548,8 +549,10 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
     """Conv backward whose incoming gradient is du + dxdbl @ wx, formed tile by tile inside the kernel (never materialised).
     x: [B, L, Dm] view; du: [ndir*B, L, Dm]; dxdbl: [ndir*B*L, P] (row stride any multiple of 8); wxt: [Dm, P] = x_proj.weight^T.
     Returns (dx_slabs [ndir*B, L, Dm] in token order, dweight [Dm, W] fp32, dbias [Dm] fp32).
-    merged_out: a [B, L, Dm] view that receives the SUM of the directions' dx (DM_FLAG_DX_MERGED: a workgroup walks the directions
-    of a sample, the first stores, the others read-add-store) -- returned in place of the slabs; no token_merge needed."""
+    merged_out: a [B, L, Dm] view that receives the SUM of the directions' dx (DM_FLAG_DX_MERGED) -- returned in place of the slabs;
+    no token_merge needed.  Two kernels behind it: sequences up to 256 rows take the slab form (a persistent workgroup per CU owns
+    128 channels, the running sum lives in LDS, dx is written once); longer ones the whole-sample form (a workgroup walks the
+    directions of a sample, the first stores, the others read-add-store)."""
     _require_gpu(x, weight, bias, du, dxdbl, wxt)
     Bsz, L, Dm = x.shape
     W = weight.shape[-1]
@@ -570,8 +573,6 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
         dx, rows = merged_out, Bsz
     else:
         dx, rows = torch.empty((S, L, Dm), dtype=x.dtype, device=dev), S
-    part = torch.empty((rows, Dm * (W + 1)), dtype=torch.float32, device=dev)     # dw | db partial rows in one buffer: one column sum
-    dw, db = part[:, :Dm * W], part[:, Dm * W:]
     a = dm_conv_xproj_bwd_args()
     a.part_ss = Dm * (W + 1)
     a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
@@ -580,16 +581,24 @@ def gather_conv1d_xproj_bwd(x, weight, bias, du, dxdbl, wxt, *, row_index=None, 
     a.nproj = P
     a.x, a.weight, a.bias, a.row_index = _ptr(x), _ptr(weight), _ptr(bias), _ptr(row_index)
     a.du, a.dxdbl, a.wxt = _ptr(du), _ptr(dxdbl), _ptr(wxt)
-    a.dx, a.dw_partial, a.db_partial = _ptr(dx), _ptr(dw), _ptr(db)
+    a.dx = _ptr(dx)
     a.x_sb, a.x_sl, a.x_sd = x.stride()
     a.du_ss, a.du_sl, a.du_sd = du.stride()
     a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
     a.xd_sr = dxdbl.stride(0)
+    # the slab form of the merged launch (running sum in LDS: no re-reads) sums dw | db per persistent workgroup stream: fewer partial rows
+    slab_rows = int(_lib.load().dm_gather_conv1d_xproj_bwd_slab(ctypes.byref(a), None)) if merged else 0
+    if slab_rows:
+        rows = slab_rows
+        a.flags |= DM_FLAG_PARTIAL_COMPACT
+    part = torch.empty((rows, Dm * (W + 1)), dtype=torch.float32, device=dev)     # dw | db partial rows in one buffer: one column sum
+    dw, db = part[:, :Dm * W], part[:, Dm * W:]
+    a.dw_partial, a.db_partial = _ptr(dw), _ptr(db)
     es = x.element_size()
-    # algorithmic bytes: x and du read per direction, dx written per direction (merged: written once -- the re-reads of the running
-    # sum are design traffic, mostly served by L2 / the Infinity Cache)
+    # algorithmic bytes: x and du read per direction, dx written per direction (merged: written once -- the whole-sample form's
+    # re-reads of the running sum are design traffic, mostly served by L2 / the Infinity Cache)
     nbytes = (2 * S + (Bsz if merged else S)) * L * Dm * es + S * L * P * es + P * Dm * es
-    _launch("dm_gather_conv1d_xproj_bwd", a, x, nbytes, nbytes + (2 * (S - Bsz) * L * Dm * es if merged else 0))
+    _launch("dm_gather_conv1d_xproj_bwd", a, x, nbytes, nbytes + (2 * (S - Bsz) * L * Dm * es if merged and not slab_rows else 0))
     psum = colsum(part)
     return dx, psum[:Dm * W].view(Dm, W), psum[Dm * W:]
 

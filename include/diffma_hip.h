@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 26
+#define DM_ABI_VERSION 27
 
 typedef enum {
     DM_OK = 0,
@@ -66,6 +66,10 @@ enum {
                                    after the other, direction 0 stores, the others read-add-store -- instead of ndir slabs for
                                    dm_token_merge to add; dw_partial / db_partial are then [batch][...] (one row per sample).
                                    Width 4, SiLU and row-index tables (the mixer's call pattern).                              */
+    DM_FLAG_PARTIAL_COMPACT = 512, /* dm_gather_conv1d_xproj_bwd, with DM_FLAG_DX_MERGED, when dm_gather_conv1d_xproj_bwd_slab(args)
+                                   returns R > 0: the caller sums only the first R rows of dw_partial / db_partial (one row per
+                                   persistent workgroup stream); without the flag the slab form zero-fills the rows of the other
+                                   samples so that a sum over all `batch` rows stays right.                                   */
     DM_FLAG_DELTA_ACTIVATED = 128 /* scan fwd / bwd: `delta` already holds softplus(raw + delta_bias) -- the producer applied it
                                    once per element (dm_dtproj_softplus_fwd) instead of every scan direction evaluating it in
                                    the forward AND in the backward.  Forward: delta is used as is, delta_bias is ignored.
@@ -287,6 +291,12 @@ typedef struct {
 
 int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args *args, void *stream);
 int dm_gather_conv1d_xproj_bwd_supported(int dim, int nproj, int io_dtype);
+/* ABI 27.  DM_FLAG_DX_MERGED launches come in two forms: the whole-sample form (a workgroup walks the directions of a sample; the
+ * running sum of dx is read back and rewritten in place per direction: 2 * (ndir-1) extra passes over [batch][seqlen][dim]) and,
+ * for seqlen <= 256 with 16-byte aligned dx rows, the SLAB form (a persistent workgroup per CU owns 128 channels, the running sum
+ * lives in LDS, dx is written once).  Returns 0 when `args` would take the whole-sample form, else R = the number of dw / db
+ * partial rows that carry sums in the slab form (rows R .. batch-1 are zero-filled, or left alone under DM_FLAG_PARTIAL_COMPACT). */
+int dm_gather_conv1d_xproj_bwd_slab(const dm_conv_xproj_bwd_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Token merge: out[b][t][c] = sum_k in[k][b][ idx[k][t] ][c]     (idx NULL = identity).

@@ -3,6 +3,7 @@
 Tolerances (SURVEY.md 8c): fp32 I/O rtol 1e-4 / atol 1e-5 vs the fp64 recurrence; bf16 I/O 3e-2 / 5e-2;
 fp16 3e-3 / 5e-3.  Integer work (row reindexing) is bit-exact.
 """
+import os
 import pytest
 import torch
 
@@ -963,15 +964,15 @@ def test_spiral_ssm_hoisted_equals_in_scan_gate(gpu, dtype, monkeypatch):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("slab", ["0", "1"])
 @pytest.mark.parametrize("Bsz,L,Dm,ndir", [(2, 196, 1024, 3), (3, 49, 128, 3), (2, 5, 1024, 2), (1, 37, 128, 4), (8, 256, 256, 3),
-                                           (16, 100, 128, 1)])
+                                           (16, 100, 128, 1), (40, 49, 1024, 3)])
 def test_fused_conv_xproj_bwd_merged_directions(gpu, monkeypatch, dtype, slab, Bsz, L, Dm, ndir):
     """K4x with DM_FLAG_DX_MERGED, both forms -- the whole-sample form (slab 0: one workgroup per sample walks the directions, dx
     accumulates in ONE token-order buffer in HBM) and the slab form (slab 1, sequences up to 256 rows: a workgroup per (sample,
     128 channels), the running sum in LDS, the gathered sequence cut into 8 segments) -- against fp64 autograd (the gradient of x
     summed over the directions), against the per-direction slabs + dm_token_merge, and dw / db from one partial row per sample.  dx
     is a strided view (the x half of d(xz)): the neighbouring z half must stay untouched.  Sequence lengths: the model's 196, one
-    with idle waves (5 rows for 8 segments), odd ones, the largest the slab form takes, a batch of 8 (its XCD-aware workgroup
-    order)."""
+    with idle waves (5 rows for 8 segments), odd ones, the largest the slab form takes, batches of 8 / 16 (the XCD-aware workgroup
+    order) and of 40 at 8 slabs (the slab form is persistent: 256 workgroups, some of which walk through two samples)."""
     from diffma_amd import hip_ops
     from oracle.mamba_ref import causal_conv1d_ref
 
@@ -1009,6 +1010,60 @@ def test_fused_conv_xproj_bwd_merged_directions(gpu, monkeypatch, dtype, slab, B
     torch.testing.assert_close(dw.cpu().double(), wd.grad, rtol=rtol, atol=atol * sc * 0.2)
     torch.testing.assert_close(db.cpu().double(), bd.grad, rtol=rtol, atol=atol * sc * 0.2)
     torch.testing.assert_close(dw.cpu(), dw2.cpu(), rtol=1e-4, atol=1e-4 * sc)
+
+
+def test_conv_xproj_bwd_slab_partial_rows_through_the_c_abi(gpu):
+    """The slab form of K4x called as a C-ABI client would: dm_gather_conv1d_xproj_bwd_slab() says how many dw | db partial rows carry
+    sums (one per persistent workgroup stream); WITHOUT DM_FLAG_PARTIAL_COMPACT the rows of the other samples are zero-filled (a sum
+    over all `batch` rows is right), WITH it only the first rows are written.  40 samples x 8 slabs: some workgroups take two samples.
+    dx must be the same buffer bit for bit in both calls and equal to the whole-sample form's within one rounding of the running sum."""
+    import ctypes
+    from diffma_amd import hip_ops, _lib
+    from diffma_amd._lib import dm_conv_xproj_bwd_args, DM_FLAG_SILU, DM_FLAG_DX_MERGED, DM_FLAG_PARTIAL_COMPACT
+
+    B, L, Dm, P, ND, W = 40, 49, 1024, 64, 3, 4
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, Dm, generator=g).to(dt).to(gpu)
+    w, b = (torch.randn(Dm, W, generator=g) * 0.5).to(gpu), (torch.randn(Dm, generator=g) * 0.1).to(gpu)
+    wxt = (torch.randn(Dm, P, generator=g) * 0.1).to(dt).to(gpu)
+    idx = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ND - 1)]).int().to(gpu)
+    du = torch.randn(ND * B, L, Dm, generator=g).to(dt).to(gpu)
+    dxd = torch.randn(ND * B * L, P, generator=g).to(dt).to(gpu)
+
+    def run(flags, slab_env, monkey_rows=None):
+        part = torch.full((B, Dm * (W + 1)), 777.0, device=gpu)
+        dx = torch.zeros(B, L, Dm, dtype=dt, device=gpu)
+        a = dm_conv_xproj_bwd_args()
+        a.part_ss = Dm * (W + 1)
+        a.batch, a.dim, a.seqlen, a.width, a.ndir = B, Dm, L, W, ND
+        a.io_dtype, a.w_dtype = hip_ops.dtype_code(x), hip_ops.dtype_code(w)
+        a.flags = DM_FLAG_SILU | DM_FLAG_DX_MERGED | flags
+        a.nproj = P
+        a.x, a.weight, a.bias, a.row_index = x.data_ptr(), w.data_ptr(), b.data_ptr(), idx.data_ptr()
+        a.du, a.dxdbl, a.wxt = du.data_ptr(), dxd.data_ptr(), wxt.data_ptr()
+        a.dx, a.dw_partial, a.db_partial = dx.data_ptr(), part.data_ptr(), part[:, Dm * W:].data_ptr()
+        a.x_sb, a.x_sl, a.x_sd = x.stride()
+        a.du_ss, a.du_sl, a.du_sd = du.stride()
+        a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
+        a.xd_sr = dxd.stride(0)
+        os.environ["DM_K4X_SLAB"] = slab_env
+        try:
+            rows = int(_lib.load().dm_gather_conv1d_xproj_bwd_slab(ctypes.byref(a), None))
+            _lib.call("dm_gather_conv1d_xproj_bwd", a, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("DM_K4X_SLAB", None)
+        return rows, dx, part
+
+    r0, dx0, p0 = run(0, "0")
+    r1, dx1, p1 = run(0, "1")
+    r2, dx2, p2 = run(DM_FLAG_PARTIAL_COMPACT, "1")
+    assert r0 == 0 and r1 == r2 == 32                                   # 256 CUs / 8 slabs = 32 streams (<= the 40 samples)
+    assert torch.equal(dx1, dx2)
+    assert float((p1[r1:] != 0).sum()) == 0 and float((p2[r2:] != 777.0).sum()) == 0 and torch.equal(p1[:r1], p2[:r2])
+    torch.testing.assert_close(dx1.float(), dx0.float(), rtol=1.6e-2, atol=1e-2 * float(dx0.float().abs().max()))
+    torch.testing.assert_close(p1.sum(0), p0.sum(0), rtol=1e-3, atol=1e-3 * float(p0.sum(0).abs().max()))
 
 
 @pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16, torch.float16])
