@@ -499,18 +499,19 @@ __global__ __launch_bounds__(XP_THREADS, 2) void conv_xproj_bwd_kernel(const dm_
 // sequence is short enough for the running sum of dx to LIVE IN LDS: seqlen <= 256 (DiffMa-*/2 at 224 px: 196 tokens).
 //
 // The kernel above gives a workgroup a whole sample: 1024 channels x 196 tokens of dx do not fit on chip, so directions 1 and 2
-// read-add-store the token-order buffer in HBM (two extra reads and two extra writes of [B, L, D]) -- 1.96 GB per launch at the
-// bench batch, which at 510 us is the 3.9 TB/s an HBM-bound pass gets here.  This one cuts the sample into SLABS of 128 channels:
-//   workgroup = (sample, slab), 8 waves;  LDS: acc[L][128] 16-bit in TOKEN order (49 KB at L = 196) + one fp32 product tile per wave;
+// read-add-store the token-order buffer in HBM (two extra reads and two extra writes of [B, L, D]) -- 2.37 GB of HBM traffic per
+// launch at the bench batch (FETCH_SIZE / WRITE_SIZE), 510-560 us.  This one cuts the sample into SLABS of 128 channels:
+//   a workgroup (8 waves) works on one (sample, slab) at a time;  LDS: acc[L][128] 16-bit in TOKEN order (49 KB at L = 196), one fp32
+//   product tile per wave, the slab's x_proj.weight^T as MFMA B-fragments, row tables;
 //   every direction adds its dx rows into acc (the rounding of the running sum is the old kernel's, step for step), a barrier
 //   separates the directions, and dx leaves ONCE, as 16-byte pieces.  Traffic: du 3x, x 1x from HBM (its two re-reads come from
-//   L2: the slab is 49 KB and the workgroup is back within microseconds), dx 1x: 1.06 GB.
+//   L2: the slab is 49 KB and the workgroup is back within microseconds), dx 1x: 1.13 GB measured.
 // A lane still owns one channel PAIR for the conv (64 lanes = the slab), so the 8 waves cut the gathered sequence into 8 SEGMENTS
 // of ceil(L / 8) rows: the conv backward needs the gradient of the 3 rows after a segment, which the wave recomputes (28 rows of
-// work for 25 at L = 196).  Rows are processed in tiles of 16 (the MFMA M) from the end of the segment to its start; the product
-// tile d x_dbl . Wx goes through the wave's own LDS tile (no workgroup barrier inside a direction).  The x_proj.weight^T
-// fragments of the slab (64 VGPRs) and two register sets of prefetched rows (x, du, d x_dbl) fit because LDS, not VGPRs, bounds
-// the occupancy here (8 waves per CU, 256 VGPRs each): the loads of tile t+1 are issued before tile t's rows are touched.
+// work for 25 at L = 196).  Rows are processed in tiles (14 or 16 rows; the MFMA M is 16) from the end of the segment to its start;
+// the product tile d x_dbl . Wx goes through the wave's own LDS tile (no workgroup barrier inside a direction).  Two register sets
+// of prefetched rows (x, du, d x_dbl) fit because LDS, not VGPRs, bounds the occupancy here (8 waves per CU, 256 VGPRs each): the
+// loads of tile t+1 are issued before tile t's rows are touched.
 // The arithmetic is written on float2 (the lane's two channels): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32.
 constexpr int XS_CS = 128;                 // channels per workgroup
 constexpr int XS_NW = 8;                   // waves = segments of the gathered sequence
