@@ -892,6 +892,10 @@ extern "C" int dm_gather_conv1d_xproj_bwd(const dm_conv_xproj_bwd_args* args, vo
     if ((a.flags & DM_FLAG_DX_MERGED) && !(a.width == 4 && (a.flags & DM_FLAG_SILU) && a.row_index)) {
         set_error("dm_gather_conv1d_xproj_bwd: DM_FLAG_DX_MERGED is built for width 4, SiLU, row-index tables"); return DM_ERR_ARG;
     }
+    if ((a.flags & DM_FLAG_PARTIAL_COMPACT) && !dm_gather_conv1d_xproj_bwd_slab(args, nullptr)) {
+        set_error("dm_gather_conv1d_xproj_bwd: DM_FLAG_PARTIAL_COMPACT is for launches dm_gather_conv1d_xproj_bwd_slab() accepts (it returned 0)");
+        return DM_ERR_ARG;
+    }
     if (!dm_gather_conv1d_xproj_bwd_supported(a.dim, a.nproj, a.io_dtype)) {
         set_error("dm_gather_conv1d_xproj_bwd: needs 16-bit I/O, dim in {128,256,512,1024}, nproj = 64 (got dim %d nproj %d dtype %d)", a.dim, a.nproj, a.io_dtype);
         return DM_ERR_ARG;

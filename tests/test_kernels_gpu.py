@@ -1057,6 +1057,8 @@ def test_conv_xproj_bwd_slab_partial_rows_through_the_c_abi(gpu):
         return rows, dx, part
 
     r0, dx0, p0 = run(0, "0")
+    with pytest.raises(_lib.DiffmaHipError, match="PARTIAL_COMPACT"):          # the whole-sample form writes `batch` rows: the flag is refused
+        run(DM_FLAG_PARTIAL_COMPACT, "0")
     r1, dx1, p1 = run(0, "1")
     r2, dx2, p2 = run(DM_FLAG_PARTIAL_COMPACT, "1")
     assert r0 == 0 and r1 == r2 == 32                                   # 256 CUs / 8 slabs = 32 streams (<= the 40 samples)
