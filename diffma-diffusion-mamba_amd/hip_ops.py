@@ -851,7 +851,10 @@ def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=
         assert x2 is None and dx_add.shape == x.shape and dx_add.dtype == x.dtype and dx_add.stride(2) == 1 and dx_add.stride(0) == L * dx_add.stride(1)
         a.dx_add, a.dxa_sr = _ptr(dx_add), dx_add.stride(1)
     assert dy1.is_contiguous() and (dy2 is None or dy2.is_contiguous())
-    _launch("dm_ln_mod_bwd", a, x, Bsz * L * C * (2 * x.element_size() + dy1.element_size() * (2 if dy2 is not None else 1)))
+    # algorithmic bytes: x read, dx written, the incoming gradient(s) read -- and the gradient dx is added to (dx_add / accumulate),
+    # which any implementation of "dx = f(x, dy) + other" has to read as well
+    has_old = dx_add is not None or bool(accumulate)
+    _launch("dm_ln_mod_bwd", a, x, Bsz * L * C * ((3 if has_old else 2) * x.element_size() + dy1.element_size() * (2 if dy2 is not None else 1)))
     if scale is None and shift is None:       # no modulation (the LayerNorm of the fusion MLP): only d gamma / d beta are wanted -- one
         pg = colsum(part.view(Bsz * bpb, 4 * C), True).view(4, C)      # column sum over all partial rows instead of two reductions
         return dx, dx2, None, None, pg[2], pg[3]
