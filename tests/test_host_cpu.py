@@ -405,3 +405,32 @@ def test_staged_backward_equals_one_backward():
                     torch.testing.assert_close(p.grad, ref[id(p)], rtol=1e-5, atol=1e-7)
     finally:
         mamba_mod.spiral_ssm = real
+
+
+def test_slab_kernel_broadcasts_from_the_low_dword_only(tmp_path):
+    """K4x slab form, DESIGN.md section 3: `float2 * float` must broadcast the LOW dword of the register pair the row-table read
+    returns (op_sel_hi).  With the table entry laid out {acc_off, own} hipcc emitted `v_pk_mul_f32 ... op_sel:[1,0]` (low result
+    from the HIGH dword) and the kernel miscounted single rows on MI355X now and then.  The built object must not contain that form
+    in the slab kernel (a compiler or source change that brings it back fails here, on the CPU, instead of sporadically on a GPU)."""
+    import re, shutil, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    obj = os.path.join(ROOT, "diffma-diffusion-mamba_amd", "csrc", "conv_xproj.o")
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    if not os.path.isfile(obj) or not all(os.path.isfile(t) for t in tools):
+        pytest.skip("needs the built conv_xproj.o and the ROCm llvm tools")
+    fat, co = str(tmp_path / "x.fat"), str(tmp_path / "x.co")
+    subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], check=True)
+    subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+    dis = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+    name, seen, bad = None, 0, []
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+        if m:
+            name = m.group(1)
+            continue
+        if name and "conv_xproj_bwd_slab_kernel" in name and re.search(r"v_pk_(mul|fma|add)_f32", line):
+            seen += 1
+            if re.search(r"op_sel:\[", line):
+                bad.append(line.strip())
+    assert seen > 1000, "the slab kernel's packed arithmetic was not found in the object"
+    assert not bad, f"low-from-high op_sel forms in the slab kernel: {bad[:3]}"
