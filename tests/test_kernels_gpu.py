@@ -1012,6 +1012,34 @@ def test_fused_conv_xproj_bwd_merged_directions(gpu, monkeypatch, dtype, slab, B
     torch.testing.assert_close(dw.cpu(), dw2.cpu(), rtol=1e-4, atol=1e-4 * sc)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("slab", ["0", "1"])
+def test_fused_conv_xproj_bwd_merged_weights_in_io_dtype(gpu, monkeypatch, dtype, slab):
+    """Conv weights handed over in the I/O dtype (the 16-bit shadows of step_prep) instead of fp32: the kernels widen them on load, so
+    with weights that are exactly representable in 16 bits both instantiations must give the same dx bit for bit and the same dw / db."""
+    from diffma_amd import hip_ops
+
+    monkeypatch.setenv("DM_K4X_SLAB", slab)
+    Bsz, L, Dm, ndir, P, W = 3, 196, 256, 3, 64, 4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(Bsz, L, Dm, generator=g).to(dtype).to(gpu)
+    w16 = (torch.randn(Dm, W, generator=g) * 0.5).to(dtype)
+    b16 = (torch.randn(Dm, generator=g) * 0.1).to(dtype)
+    wxt = (torch.randn(Dm, P, generator=g) * 0.1).to(dtype).to(gpu)
+    perms = torch.stack([torch.arange(L)] + [torch.randperm(L, generator=g) for _ in range(ndir - 1)]).int().to(gpu)
+    du = torch.randn(ndir * Bsz, L, Dm, generator=g).to(dtype).to(gpu)
+    dxdbl = torch.randn(ndir * Bsz * L, P, generator=g).to(dtype).to(gpu)
+    outs = []
+    for wt, bt in ((w16.float(), b16.float()), (w16, b16)):
+        dx = torch.zeros(Bsz, L, Dm, dtype=dtype, device=gpu)
+        _, dw, db = hip_ops.gather_conv1d_xproj_bwd(x, wt.to(gpu), bt.to(gpu), du, dxdbl, wxt, row_index=perms, ndir=ndir, merged_out=dx)
+        outs.append((dx, dw, db))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0][0], outs[1][0])
+    torch.testing.assert_close(outs[0][1], outs[1][1], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-6, atol=1e-6)
+
+
 def test_conv_xproj_bwd_slab_partial_rows_through_the_c_abi(gpu):
     """The slab form of K4x called as a C-ABI client would: dm_gather_conv1d_xproj_bwd_slab() says how many dw | db partial rows carry
     sums (one per persistent workgroup stream); WITHOUT DM_FLAG_PARTIAL_COMPACT the rows of the other samples are zero-filled (a sum
