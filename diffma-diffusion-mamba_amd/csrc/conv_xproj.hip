@@ -632,25 +632,33 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
     // for an old one: no prefetch left).  Bases: 64-bit products are formed on the vector unit by this compiler; xs_uniform64 brings
     // them back to SGPRs (an address left in VGPRs costs a waterfall loop per load).
     auto tokens = [&](int dir, int t) -> int { return xtok[dir][a + RT * t + (lane < NXR ? lane : NXR - 1)]; };
-    auto issue = [&](int bb, int dir, int t, bool live, int tokv, xs_bufs<T, RT>& o) {
+    auto issue = [&](int bb, int dir, int t, bool live, int tokv, xs_bufs<T, RT>& o) {       // d x_dbl and x rows of a tile
         const int l0 = a + RT * t;
         const int vo_l = live ? vo : BIO_OOB;
         const int s = dir * p.batch + bb;
         const rsrc_t r_x = make_rsrc_2g((const T*)p.x + xs_uniform64((int64_t)bb * p.x_sb + c0));
-        const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.du + xs_uniform64((int64_t)s * p.du_ss + c0)), 0, du_bytes, 0x00020000);
         const rsrc_t r_xd = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.dxdbl + xs_uniform64((int64_t)s * L * p.xd_sr)), 0, xd_bytes, 0x00020000);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, live ? (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES : BIO_OOB, 0, 0);
+            const auto q = __builtin_amdgcn_raw_buffer_load_b128(r_xd, (l0 + ij) * sr_xd + (32 * kk + 8 * g) * ES + (live ? 0 : BIO_OOB), 0, 0);   // (a sum: a select on the uniform flag becomes a branch)
             o.a[kk] = (xp_u32x4){q[0], q[1], q[2], q[3]};
         }
 #pragma unroll
         for (int j = NXR - 1; j >= 0; --j) o.x[j] = __builtin_amdgcn_raw_buffer_load_b32(r_x, vo_l, __builtin_amdgcn_readlane(tokv, j) * sl_x, 0);
+    };
+    // du is the stream that comes from HBM: its rows are requested TWO tiles ahead, half a tile at a time, into the registers the
+    // tile in work has just consumed (the two register sets alternate, so the tile after next uses this one's)
+    auto issue_du = [&](int bb, int dir, int t, bool live, int hh, xs_bufs<T, RT>& o) {
+        const int l0 = a + RT * t;
+        const int vo_l = live ? vo : BIO_OOB;
+        const int s = dir * p.batch + bb;
+        const rsrc_t r_du = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>((const T*)p.du + xs_uniform64((int64_t)s * p.du_ss + c0)), 0, du_bytes, 0x00020000);
 #pragma unroll
-        for (int j = RT - 1; j >= 0; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
+        for (int j = (hh + 1) * HR - 1; j >= hh * HR; --j) o.du[j] = __builtin_amdgcn_raw_buffer_load_b32(r_du, vo_l, (l0 + j) * sl_du, 0);
     };
     // one tile: product on the matrix pipe into the wave's LDS tile, the next tile's loads, then the rows, last first
-    auto step = [&](int bb, int dir, int t, bool more, int b_n, int dir_n, int t_n, xs_bufs<T, RT>& cur, xs_bufs<T, RT>& nxt) {
+    auto step = [&](int bb, int dir, int t, bool more, int b_n, int dir_n, int t_n, bool more2, int b_2, int dir_2, int t_2,
+                    xs_bufs<T, RT>& cur, xs_bufs<T, RT>& nxt) {
         const int l0 = a + RT * t;
         const xs_row* const rw = rt + (dir * nt + t) * RT;
         if (t == nt - 1) {
@@ -658,9 +666,8 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
             for (int k = 0; k < W - 1; ++k) gnext[k] = (f32x2){0.f, 0.f};         // a new sequence: no later rows yet
         }
         const int tok_n = tokens(more ? dir_n : 0, more ? t_n : 0);
-        // this tile's rows were requested a whole tile ago: all of them have to be here now (and two sets of 35 loads in flight
-        // would overrun the 6-bit vmcnt counter); the next tile's go out at once, ahead of the product
-        __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0)
+        // the next tile's d x_dbl and x rows go out at once, ahead of the product (at most 19 + 2 x 14 loads are in flight: inside the
+        // 6-bit vmcnt counter, and every load is unconditional, so the compiler's waits are exact)
         issue(more ? b_n : bb, more ? dir_n : 0, more ? t_n : 0, more, tok_n, nxt);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -701,6 +708,7 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
             }
 #pragma unroll
             for (int k = 0; k < W - 1; ++k) gnext[k] = gv[k];
+            issue_du(more2 ? b_2 : bb, more2 ? dir_2 : 0, more2 ? t_2 : 0, more2, h, cur);      // this half's du registers are free
             // ---- dx[m] = sum_j w[j] * g[m + (W-1) - j], added to the token-order running sum (the rows of a direction are distinct tokens) ----
             uint32_t* ap[HR];
             uint32_t old[HR];
@@ -738,7 +746,6 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
 
     __syncthreads();                                                              // acc zeroed, tables and fragments in place
     xs_bufs<T, RT> bufA, bufB;
-    issue(b_first, 0, nt - 1, true, tokens(0, nt - 1), bufA);
     // the tile after (bb, dir, t)
     auto after = [&](int bb, int dir, int t, int& b2, int& d2, int& t2) {
         b2 = bb; d2 = dir; t2 = t - 1;
@@ -746,13 +753,24 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
         if (d2 == p.ndir) { d2 = 0; b2 = bb + bstep; }
     };
     int bb = b_first, dir = 0, t = nt - 1;
-    while (bb < p.batch) {
-        int b1, d1, t1, b2, d2, t2;
+    {
+        int b1, d1, t1;
         after(bb, dir, t, b1, d1, t1);
-        step(bb, dir, t, b1 < p.batch, b1, d1, t1, bufA, bufB);
-        if (b1 >= p.batch) break;
+        issue(bb, dir, t, true, tokens(dir, t), bufA);
+        issue_du(bb, dir, t, true, 1, bufA);
+        issue_du(bb, dir, t, true, 0, bufA);
+        const bool m1 = b1 < p.batch;
+        issue_du(m1 ? b1 : bb, m1 ? d1 : 0, m1 ? t1 : 0, m1, 1, bufB);
+        issue_du(m1 ? b1 : bb, m1 ? d1 : 0, m1 ? t1 : 0, m1, 0, bufB);
+    }
+    while (bb < p.batch) {
+        int b1, d1, t1, b2, d2, t2, b3, d3, t3;
+        after(bb, dir, t, b1, d1, t1);
         after(b1, d1, t1, b2, d2, t2);
-        step(b1, d1, t1, b2 < p.batch, b2, d2, t2, bufB, bufA);
+        step(bb, dir, t, b1 < p.batch, b1, d1, t1, b2 < p.batch, b2, d2, t2, bufA, bufB);
+        if (b1 >= p.batch) break;
+        after(b2, d2, t2, b3, d3, t3);
+        step(b1, d1, t1, b2 < p.batch, b2, d2, t2, b3 < p.batch, b3, d3, t3, bufB, bufA);
         bb = b2; dir = d2; t = t2;
     }
     {   // dw | db: the 8 segments' sums through LDS (the product tiles are free), into the partial row of the first sample; zeros into
