@@ -270,6 +270,9 @@ extern "C" int dm_gemm_n(const dm_gemm_args* args, int n, void* stream) {
     if (!args || n <= 0) { set_error("dm_gemm_n: null args / n <= 0"); return DM_ERR_ARG; }
     return mix_launch_n(args, n, [&](const dm_gemm_args* a) { return dm_gemm(a, stream); },
                         [](const dm_gemm_args& x, const dm_gemm_args& y) {
-                            return mix_congruent(x, y, &dm_gemm_args::a, &dm_gemm_args::b, &dm_gemm_args::c);
+                            // dm_gemm validates args[i] only: a second struct rides along only with the same 16-byte alignment
+                            auto al = [](const void* p, const void* q) { return (((uintptr_t)p ^ (uintptr_t)q) & 15) == 0; };
+                            return al(x.a, y.a) && al(x.b, y.b) && al(x.c, y.c) &&
+                                   mix_congruent(x, y, &dm_gemm_args::a, &dm_gemm_args::b, &dm_gemm_args::c);
                         });
 }

@@ -339,7 +339,11 @@ extern "C" int dm_colsum_f32_n(const dm_colsum_args* args, int n, void* stream) 
     using namespace dm;
     if (!args || n <= 0) { set_error("dm_colsum_f32_n: null args / n <= 0"); return DM_ERR_ARG; }
     return mix_launch_n(args, n, [&](const dm_colsum_args* a) { return dm_colsum_f32(a, stream); },
-                        [](const dm_colsum_args& x, const dm_colsum_args& y) { return mix_congruent(x, y, &dm_colsum_args::in, &dm_colsum_args::out); });
+                        [](const dm_colsum_args& x, const dm_colsum_args& y) {
+                            // the single entry validates args[i] only: the second struct must have the alignment of the first
+                            return same_align16(x.in, y.in) && same_align16(x.out, y.out) &&
+                                   mix_congruent(x, y, &dm_colsum_args::in, &dm_colsum_args::out);
+                        });
 }
 
 extern "C" int dm_sum_partials_n(const dm_sum_partials_args* args, int n, void* stream) {
@@ -347,6 +351,7 @@ extern "C" int dm_sum_partials_n(const dm_sum_partials_args* args, int n, void* 
     if (!args || n <= 0) { set_error("dm_sum_partials_n: null args / n <= 0"); return DM_ERR_ARG; }
     return mix_launch_n(args, n, [&](const dm_sum_partials_args* a) { return dm_sum_partials(a, stream); },
                         [](const dm_sum_partials_args& x, const dm_sum_partials_args& y) {
-                            return mix_congruent(x, y, &dm_sum_partials_args::in, &dm_sum_partials_args::out);
+                            return same_align16(x.in, y.in) && same_align16(x.out, y.out) &&
+                                   mix_congruent(x, y, &dm_sum_partials_args::in, &dm_sum_partials_args::out);
                         });
 }

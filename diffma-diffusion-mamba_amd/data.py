@@ -155,9 +155,11 @@ def prepare_batch(x_ct, z_mri, encoders: Encoders, ct_encoder, device, encode_ta
     encode_target=False (sampling: only the conditioning is needed) skips the VAE encode of the MRI target; z is then None."""
     x_ct = torch.cat([x_ct] * 3, dim=1).to(device) if x_ct.shape[1] == 1 else x_ct.to(device)
     z_mri = torch.cat([z_mri] * 3, dim=1).to(device) if z_mri.shape[1] == 1 else z_mri.to(device)
-    if not torch.all((z_mri >= -1) & (z_mri <= 1)):
-        z_mri = ((z_mri - z_mri.min()) * 1.0 / (z_mri.max() - z_mri.min())) * 2.0 - 1.0
-    z = encoders.vae_encode(z_mri) if encode_target else None
+    z = None
+    if encode_target:         # (sampling never reads the target: no renormalisation pass, no host-synchronising range check)
+        if not torch.all((z_mri >= -1) & (z_mri <= 1)):
+            z_mri = ((z_mri - z_mri.min()) * 1.0 / (z_mri.max() - z_mri.min())) * 2.0 - 1.0
+        z = encoders.vae_encode(z_mri)
     x_lat = encoders.vae_encode(x_ct)
     w, y2 = ct_encoder(x_lat)
     y = encoders.clip_embed(x_ct)

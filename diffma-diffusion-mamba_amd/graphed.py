@@ -247,7 +247,13 @@ class GraphedTrainStep:
         self.staged = None
         if self.split and stages and hasattr(model, "blocks") and hasattr(model, "final_layer") and len(model.blocks) >= 2 * 4 \
                 and len(model.blocks) % 4 == 0 and type(model.blocks[0]).__name__ == "Spiral_MambaBlock":
-            self.staged = StagedBackward(model, per=len(model.blocks) // max(2, min(int(stages), len(model.blocks) // 4)))
+            # the stage count is rounded DOWN to a divisor of the depth (depth 16, stages 3 -> 2 stages of 8 blocks); without one
+            # (>= 2 stages of >= 4 blocks) the step stays in the two-graph form instead of raising at construction
+            depth = len(model.blocks)
+            want = max(2, min(int(stages), depth // 4))
+            nst = next((k for k in range(want, 1, -1) if depth % k == 0 and depth // k >= 4), 0)
+            if nst:
+                self.staged = StagedBackward(model, per=depth // nst)
         self._gp = [p for p in model.parameters() if p.requires_grad]
         # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
         # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
@@ -302,6 +308,7 @@ class GraphedTrainStep:
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.copy_(o_snap[id(v)]) if id(v) in o_snap else v.zero_()
+            self.skipped.zero_()        # the warm-up iterations ran on restored state: their dropped steps are not the run's
 
     def _step(self):
         with torch.autocast("cuda", dtype=self.amp, enabled=self.amp is not None):
@@ -413,4 +420,8 @@ class GraphedTrainStep:
         # a replayed optimizer updates A_log without bumping its version counter: drop the mixers' no-grad cache of -exp(A_log)
         for m in self._mixers:
             m.__dict__.pop("_A_cache", None)
+        # ... and the 16-bit weight copies of step_prep are one optimizer step old for any EAGER forward that follows (the replayed
+        # graph refreshes them itself at its top): mark them stale
+        from . import step_prep
+        step_prep.invalidate()
         return self.sloss

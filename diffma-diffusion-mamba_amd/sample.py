@@ -104,7 +104,8 @@ def main(args):
         if real is not None:
             with torch.no_grad():
                 real["decoded"].append(real["enc"].vae_decode(samples / VAE_SCALE).cpu())      # reference sample.py:108
-    torch.save(torch.cat(out), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))
+    # (an empty shard -- more ranks than validation items -- writes an empty tensor instead of failing in torch.cat)
+    torch.save(torch.cat(out) if out else torch.empty(0, 4, latent, latent), os.path.join(args.save_dir, f"latents_rank{rank}.pt"))
     if real is not None and real["decoded"]:
         torch.save(torch.cat(real["decoded"]), os.path.join(args.save_dir, f"images_rank{rank}.pt"))
     if dist.is_initialized():

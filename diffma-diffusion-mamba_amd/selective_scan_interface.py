@@ -980,8 +980,12 @@ def _const(kind, n, device):
     key = (kind, int(n), str(device))
     t = _CONSTS.get(key)
     if t is None:
-        t = torch.arange(n, device=device, dtype=torch.int32)[None] if kind == "ident" else torch.zeros(n, device=device)
-        _CONSTS[key] = t
+        # created OUTSIDE inference mode (an inference tensor cannot be saved for a later backward); not cached while a stream is
+        # capturing (the tensor would live in that graph's private pool) -- ADVICE r4
+        with torch.inference_mode(False):
+            t = torch.arange(n, device=device, dtype=torch.int32)[None] if kind == "ident" else torch.zeros(n, device=device)
+        if not (torch.device(device).type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _CONSTS[key] = t
     return t
 
 

@@ -18,7 +18,8 @@ import torch
 
 ENABLED = os.environ.get("DIFFMA_STEP_PREP", "1") == "1"
 _PLANS = weakref.WeakKeyDictionary()
-_SHADOWS = {}            # id(master) -> (weakref to the master, shadow tensor, master version when copied); the weakref guards against
+_GEN = [0]               # bumped by invalidate(): weights changed behind autograd's back (a hipGraph replay of the optimizer, `.data` writes)
+_SHADOWS = {}            # id(master) -> (weakref to the master, shadow tensor, master version when copied, _GEN then); the weakref guards against
                          # id() reuse after a model is freed (a NEW parameter with the id and version of a dead one must not get its shadow)
                          # and its callback drops the entry (and with it the shadow's device memory) when the master dies
 
@@ -31,7 +32,15 @@ def _register(w, shadow):
         if ent is not None and ent[0] is ref:
             del _SHADOWS[key]
 
-    _SHADOWS[key] = (weakref.ref(w, _gone), shadow, w._version)
+    _SHADOWS[key] = (weakref.ref(w, _gone), shadow, w._version, _GEN[0])
+
+
+def invalidate():
+    """Every 16-bit copy made so far is stale from now on.  For writers that do not bump `_version`: a replayed hipGraph of the fused
+    AdamW (graphed.GraphedTrainStep.step calls this next to dropping `_A_cache`), `.data` assignments.  The next eager prepare() then
+    re-casts the masters and cast_weight() falls back to a fresh cast until it has (before this an eager grad-enabled
+    forward after a replay multiplied by weight copies one optimizer step old)."""
+    _GEN[0] += 1
 
 
 class _NegExpAll(torch.autograd.Function):
@@ -67,7 +76,7 @@ def shadow_of(weight, dtype):
     if ent[0]() is not weight:                      # the entry belongs to a parameter that no longer exists
         del _SHADOWS[id(weight)]
         return None
-    if ent[2] == weight._version and ent[1].dtype == dtype and ent[1].device == weight.device and ent[1].shape == weight.shape:
+    if ent[3] == _GEN[0] and ent[2] == weight._version and ent[1].dtype == dtype and ent[1].device == weight.device and ent[1].shape == weight.shape:
         return ent[1]
     return None
 

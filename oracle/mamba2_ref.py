@@ -34,7 +34,7 @@ def ssd_scan_ref(x, dt, A, Bm, Cm, D, headdim, dtype=torch.float64):
     Bsz, L, dim = x.shape
     H = dim // headdim
     xh = x.view(Bsz, L, H, headdim)
-    S = torch.zeros(Bsz, H, headdim, Bm.shape[-1], dtype=dtype)
+    S = torch.zeros(Bsz, H, headdim, Bm.shape[-1], dtype=dtype, device=x.device)
     ys = []
     for l in range(L):
         a = torch.exp(dt[:, l] * A[None])                                        # (B, H)

@@ -50,7 +50,7 @@ def selective_scan_ref(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta
     rep = dim // G
     Bm = Bm.repeat_interleave(rep, dim=1)  # (B, D, N, L)
     Cm = Cm.repeat_interleave(rep, dim=1)
-    h = torch.zeros(bsz, dim, N, dtype=dtype)
+    h = torch.zeros(bsz, dim, N, dtype=dtype, device=u.device)
     ys = []
     for l in range(L):
         dl = delta[:, :, l]                                  # (B, D)

@@ -347,6 +347,17 @@ def test_step_prep_shadows_survive_two_forwards_and_a_retained_graph():
         step_prep.prepare(m, dtype=torch.bfloat16)
         assert step_prep.shadow_of(W, torch.bfloat16) is s1
         torch.testing.assert_close(s1.float(), W.detach().to(torch.bfloat16).float())
+        # a writer that does not bump `_version` (a replayed hipGraph of the optimizer; here `.data`): invalidate() is what the
+        # graphed step calls -- the copies are stale until the next prepare(), which re-casts them
+        W.data.mul_(2.0)
+        assert step_prep.shadow_of(W, torch.bfloat16) is s1              # the hazard: the version did not move
+        step_prep.invalidate()
+        assert step_prep.shadow_of(W, torch.bfloat16) is None
+        torch.testing.assert_close(step_prep.cast_weight(W, torch.bfloat16).float(), W.detach().to(torch.bfloat16).float())
+        step_prep.prepare(m, dtype=torch.bfloat16)
+        s2 = step_prep.shadow_of(W, torch.bfloat16)
+        assert s2 is not None
+        torch.testing.assert_close(s2.float(), W.detach().to(torch.bfloat16).float())
     # a dead master takes its entry (and the shadow's memory) with it
     key = id(W)
     assert key in step_prep._SHADOWS

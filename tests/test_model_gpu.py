@@ -1033,7 +1033,7 @@ def test_step_prep_is_bitwise_neutral(gpu, monkeypatch):
     import weakref
     dead = torch.nn.Parameter(torch.zeros(4, 4, device=gpu))
     fresh = torch.nn.Parameter(torch.ones(4, 4, device=gpu))
-    step_prep._SHADOWS[id(fresh)] = (weakref.ref(dead), torch.zeros(4, 4, device=gpu, dtype=torch.bfloat16), fresh._version)
+    step_prep._SHADOWS[id(fresh)] = (weakref.ref(dead), torch.zeros(4, 4, device=gpu, dtype=torch.bfloat16), fresh._version, step_prep._GEN[0])
     assert step_prep.shadow_of(fresh, torch.bfloat16) is None and id(fresh) not in step_prep._SHADOWS
 
 
@@ -1153,3 +1153,101 @@ def test_paired_mixers_equal_two_unpaired_mixers_and_halve_the_launches(gpu, mon
         assert rel_l2(g1[k], g0[k]) <= 3e-2, (k, rel_l2(g1[k], g0[k]))
     # block-level kernels (LayerNorms, gate head, blend) are unchanged; the mixers' share of the C-ABI launches halves
     assert n1 < n0 and (n0 - n1) >= 10, (n0, n1)
+
+
+def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
+    """The composition the bench times, end to end, with NO thresholds patched: a depth-2 DiffMa at the L/2
+    width (hidden 512 -> d_inner 1024, dt_rank 32 = hidden / 16, 28 x 28 latents -> L = 196), batch 176 (3 x 176 = 528 sequences >= 512), bf16
+    autocast, forward + `training_losses` backward.  At this launch size the library selects K3x (fused conv + x_proj), the K4x slab
+    form, the sequential scans K1 / K2, K8 / K8b, the split-K weight gradients and the large-batch projections; the launch log
+    below asserts that they are what ran.  Reference arithmetic: fp64 autograd through oracle.model_ref (the fp64 oracle runs ON
+    THE DEVICE here, 16 samples at a time -- its sequential scan keeps ~0.6 GB per sample for autograd -- and its parameter
+    gradients are summed over the chunks; it is the checker, not the path).  Bounds: output rel-L2 <= 2e-2, every parameter gradient
+    rel-L2 <= 6e-2 (bf16 activations, fp32 master weights)."""
+    from diffma_amd import _lib, hip_ops
+    from diffma_amd import selective_scan_interface as ssi
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa
+    from oracle.model_ref import diffma_forward_ref
+
+    log = []
+    real_call, real_call_n = _lib.call, _lib.call_n
+
+    def call(name, a, st):
+        log.append((name, a))
+        return real_call(name, a, st)
+
+    def call_n(name, arr, st):
+        log.extend((name, a) for a in arr)
+        return real_call_n(name, arr, st)
+
+    monkeypatch.setattr(_lib, "call", call)
+    monkeypatch.setattr(_lib, "call_n", call_n)
+    tn = []
+    real_tn = ssi._tn_splitk_impl
+    monkeypatch.setattr(ssi, "_tn_splitk_impl", lambda a, b: (tn.append((a.shape[0], a.shape[1], b.shape[1])), real_tn(a, b))[1])
+
+    torch.manual_seed(11)
+    depth, B, L = 2, 176, 196
+    net = DiffMa(input_size=28, patch_size=2, hidden_size=512, depth=depth, dt_rank=16, d_state=16)
+    _rerandomize(net, 12)
+    g = torch.Generator().manual_seed(13)
+    x, y, y2 = torch.randn(B, 4, 28, 28, generator=g), torch.randn(B, 512, generator=g), torch.randn(B, L, 512, generator=g)
+    w = torch.sigmoid(torch.randn(B, L, 1, generator=g))
+    t = torch.randint(0, 1000, (B,), generator=g)
+    nz = torch.randn(B, 4, 28, 28, generator=g)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(gpu).train()
+    d = create_diffusion("")
+    dev = lambda v: v.to(gpu)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(dev(x), dev(t), y=dev(y), y2=dev(y2), w=dev(w))
+        n_fwd = len(log)
+        loss = d.training_losses(net, dev(x), dev(t), dict(y=dev(y), y2=dev(y2), w=dev(w)), noise=dev(nz))["loss"].mean()
+    del log[:n_fwd]                                            # keep the training step's launches only
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {k: p.grad.detach().double() for k, p in net.named_parameters() if p.grad is not None}
+
+    # ---- what ran ------------------------------------------------------------------------------------------------------------
+    names = [n for n, _ in log]
+    nmix = 2 * depth
+    assert names.count("dm_gather_conv1d_xproj_fwd") == nmix, names.count("dm_gather_conv1d_xproj_fwd")          # K3x
+    assert names.count("dm_gather_conv1d_xproj_bwd") == nmix                                                     # K4x ...
+    lib = _lib.load()
+    import ctypes
+    for n, a in log:
+        if n == "dm_gather_conv1d_xproj_bwd":
+            assert a.batch == B and a.ndir == 3 and lib.dm_gather_conv1d_xproj_bwd_slab(ctypes.byref(a), None) > 0   # ... in its slab form
+        if n in ("dm_selective_scan_fwd", "dm_selective_scan_bwd"):
+            # the library's rule (csrc/scan_fwd_chunked.h use_chunked_fwd, scan_bwd_chunked.h): more than 512 channel-waves -> sequential
+            assert a.nseq == 3 * B and a.nseq * ((a.dim + 63) // 64) > 512 and not (a.flags & _lib.DM_FLAG_SCAN_CHUNKED)
+    assert names.count("dm_selective_scan_fwd") == nmix and names.count("dm_selective_scan_bwd") == nmix          # K1, K2
+    assert names.count("dm_dtproj_softplus_fwd") == nmix and names.count("dm_dtproj_bwd") == nmix                 # K8, K8b
+    assert "dm_gather_conv1d_fwd" not in names and "dm_gather_conv1d_bwd" not in names                            # not the unfused pair
+    assert not any(n == "dm_gemm" and max(a.P, a.Q) <= 3200 and a.Kc <= 3200 for n, a in log)                     # not the small-launch GEMM
+    # split-K weight gradients over M = B L rows (in_proj, out_proj, the fusion MLP) and 3 B L rows (x_proj)
+    assert sum(1 for m, _, _ in tn if m == B * L) >= 2 * nmix and sum(1 for m, _, _ in tn if m == 3 * B * L) == nmix, tn
+
+    # ---- the oracle, fp64, on the device, 16 samples at a time ------------------------------------------------------------------
+    sd64 = {k: v.double().to(gpu).requires_grad_(k != "pos_embed") for k, v in sd.items()}
+    model = lambda xx, tt, **kws: diffma_forward_ref(sd64, xx, tt, kws["y"], kws["y2"], kws["w"], patch_size=2, depth=depth, dtype=torch.float64)
+    ref_out, ref_loss = [], 0.0
+    for i in range(0, B, 16):
+        s = slice(i, i + 16)
+        c = lambda v: v[s].double().to(gpu)
+        with torch.no_grad():
+            ref_out.append(model(c(x), dev(t[s]), y=c(y), y2=c(y2), w=c(w)))
+        part = d.training_losses(model, c(x), dev(t[s]), dict(y=c(y), y2=c(y2), w=c(w)), noise=c(nz))["loss"].sum() / B
+        part.backward()
+        ref_loss += float(part.detach())
+    ref_out = torch.cat(ref_out).detach()
+    assert float(ref_out.abs().mean()) > 1e-3
+    assert rel_l2(out.detach().float().cpu(), ref_out.cpu()) <= 2e-2, rel_l2(out.detach().float().cpu(), ref_out.cpu())
+    assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
+    worst = {}
+    for k, gr in got.items():
+        worst[k] = rel_l2(gr.cpu(), sd64[k].grad.cpu())
+    bad = {k: v for k, v in worst.items() if not v <= 6e-2}
+    assert not bad, bad
+    assert len(got) == sum(1 for k in sd64 if k != "pos_embed")
