@@ -141,7 +141,7 @@ def load():
                 fn.argtypes = [ctypes.c_int] * 5
             elif name in ("dm_gather_conv1d_xproj_supported", "dm_gather_conv1d_xproj_bwd_supported", "dm_dtproj_softplus_supported", "dm_dtproj_bwd_supported"):
                 fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
-            elif name == "dm_gemm_supported":
+            elif name in ("dm_gemm_supported", "dm_gemm_large_supported"):
                 fn.argtypes = [ctypes.c_int] * 7
             elif name.endswith("_n"):                    # an array of n argument structs (several congruent launches in one)
                 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]

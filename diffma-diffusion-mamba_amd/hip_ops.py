@@ -793,6 +793,47 @@ def gemm(a, b, a_kmajor=True, b_kmajor=True, out=None, out_dtype=None, accumulat
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# Dense products of the projections at LARGE batch (csrc/gemm_large.hip, K12): persistent 256 x 256 tiles, both operands k-major
+# ------------------------------------------------------------------------------------------------
+GEMM_LARGE = os.environ.get("DIFFMA_GEMM_LARGE", "1") == "1"      # 0: the library GEMMs again (A/B runs)
+
+
+def gemm_large_supported(a, b, out=None):
+    """a [P, Kc], b [Q, Kc] stored matrices (column stride 1), 16-bit, for C = a @ b^T in the operand dtype."""
+    if not (GEMM_LARGE and a.is_cuda and a.dtype in (torch.bfloat16, torch.float16) and b.dtype == a.dtype and a.dim() == 2 and b.dim() == 2):
+        return False
+    if a.stride(1) != 1 or b.stride(1) != 1 or a.stride(0) % 8 or b.stride(0) % 8 or a.data_ptr() % 16 or b.data_ptr() % 16:
+        return False
+    if a.shape[1] != b.shape[1]:
+        return False
+    if out is not None and (out.dtype != a.dtype or out.stride(1) != 1 or out.stride(0) % 8 or out.data_ptr() % 16):
+        return False
+    big = max((a.shape[0] + 256) * a.stride(0), b.shape[0] * b.stride(0), (a.shape[0] + 256) * (out.stride(0) if out is not None else b.shape[0]))
+    if big * 2 >= 0x7ffffff0:
+        return False
+    code = dtype_code(a)
+    return bool(_lib.load().dm_gemm_large_supported(a.shape[0], b.shape[0], a.shape[1], 1, 1, code, code))
+
+
+def gemm_large(a, b, out=None):
+    """C[P, Q] = a @ b^T (a [P, Kc], b [Q, Kc]) by the persistent large-batch kernel; the caller checked gemm_large_supported."""
+    _require_gpu(a, b)
+    P, Kc = a.shape
+    Q = b.shape[0]
+    if out is None:
+        out = torch.empty((P, Q), dtype=a.dtype, device=a.device)
+    g = dm_gemm_args()
+    g.P, g.Q, g.Kc = P, Q, Kc
+    g.ab_dtype, g.c_dtype = dtype_code(a), dtype_code(out)
+    g.a_kmajor, g.b_kmajor = 1, 1
+    g.accumulate = 0
+    g.a, g.b, g.c = _ptr(a), _ptr(b), _ptr(out)
+    g.lda, g.ldb, g.ldc = a.stride(0), b.stride(0), out.stride(0)
+    _launch("dm_gemm_large", g, a, (P * Kc + Q * Kc) * a.element_size() + P * Q * out.element_size(), flops=2 * P * Q * Kc)
+    return out
+
+
 LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK
 
 

@@ -216,6 +216,29 @@ def _own_single(a, b, a_kmajor, b_kmajor, out_dtype=None):
             and hip_ops.gemm_supported(a, b, a_kmajor, b_kmajor, out_dtype))
 
 
+# Large-batch projections on K12 (csrc/gemm_large.hip).  DIFFMA_GEMM_LARGE=0 (hip_ops.GEMM_LARGE) returns every product to the library.
+# DIFFMA_GEMM_LARGE_MIN_COLS: K12 is taken from this many output columns.  Measured against the TunableOp-tuned library at M = 100 352
+# (profiles/r05_gemm_large_ablation.txt, stand-alone): N = 2048 and 1024 level or ahead (in_proj forward 216 vs 222 us, out_proj
+# input gradient 108 vs 125 / 148 us), N = 512 level (out_proj forward 104 vs 105) or behind (in_proj input gradient, K = 2048: 223 vs
+# 198).  Inside the training step K12's launches run ~10 % longer than stand-alone and the step is 0.5 % SLOWER with K12 on the two
+# wide products than with the library everywhere (220.1 vs 219.1 ms, same box; 221.9 with K12 on all four): at parity, not ahead.
+# The default keeps it on the wide products; DIFFMA_GEMM_LARGE_MIN_COLS=512 puts all four on it.
+LARGE_MIN_ROWS = int(os.environ.get("DIFFMA_GEMM_LARGE_MIN_ROWS", "12288"))
+LARGE_MIN_COLS = int(os.environ.get("DIFFMA_GEMM_LARGE_MIN_COLS", "1024"))
+LARGE_MAX_K_NARROW = int(os.environ.get("DIFFMA_GEMM_LARGE_MAX_K_NARROW", "1024"))     # for outputs narrower than 1024 columns
+# dx = dy W as dy (W^T)^T with a transposed 16-bit weight copy: the library's NT kernels beat its NN kernels at these shapes
+LARGE_DGRAD_NT = os.environ.get("DIFFMA_DGRAD_NT", "1") == "1"
+
+
+def _own_large(a, b):
+    """dm_gemm_large for C = a @ b^T (a [M, K], b [N, K], both 16-bit, K contiguous)?"""
+    M, K = a.shape
+    N = b.shape[0]
+    if M < LARGE_MIN_ROWS or N < LARGE_MIN_COLS or (N < 1024 and K > LARGE_MAX_K_NARROW):
+        return False
+    return hip_ops.gemm_large_supported(a, b)
+
+
 class _LinearSplitKFn(torch.autograd.Function):
     """F.linear whose weight gradient uses the split-K product above (the projections' dW GEMMs have K = B*L)."""
 
@@ -230,6 +253,9 @@ class _LinearSplitKFn(torch.autograd.Function):
         if bias is None and xc.is_cuda and _own_single(xc.reshape(-1, xc.shape[-1]), wc, True, True):
             # small launches: the own kernel is faster than the library's quantised tile grid (csrc/gemm.hip)
             return hip_ops.gemm(xc.reshape(-1, xc.shape[-1]), wc).view(*xc.shape[:-1], wc.shape[0])
+        if bias is None and xc.is_cuda and _own_large(xc.reshape(-1, xc.shape[-1]), wc):
+            # large batch: the persistent 256 x 256 kernel (csrc/gemm_large.hip, K12)
+            return hip_ops.gemm_large(xc.reshape(-1, xc.shape[-1]), wc).view(*xc.shape[:-1], wc.shape[0])
         return GemmChain.run(F.linear, xc, wc, None if bias is None else cast_weight(bias, dt_))
 
     @staticmethod
@@ -246,6 +272,15 @@ class _LinearSplitKFn(torch.autograd.Function):
                 dx = None
             elif b_dt is None and _own_single(dy2c, wc, True, False):
                 dx = hip_ops.gemm(dy2c, wc, True, False).view(xc.shape).to(x_dt)
+            elif LARGE_DGRAD_NT and dy2c.is_cuda and dy2c.shape[0] >= LARGE_MIN_ROWS and dy2c.dtype in (torch.bfloat16, torch.float16):
+                # dx = dy W as an "NT" product with a transposed 16-bit copy of the weight (a few MB, one small launch): both
+                # operands then have the contraction index contiguous.  Measured at M = 100 352 (tools/bench_gemm_large.py): the
+                # library's NN form 217 / 148 us (in_proj / out_proj) against 198 / 125 us for its NT form and 223 / 108 us for K12.
+                wt = wc.t().contiguous()
+                if _own_large(dy2c, wt):
+                    dx = hip_ops.gemm_large(dy2c, wt).view(xc.shape).to(x_dt)
+                else:
+                    dx = GemmChain.run(F.linear, dy2c, wt).view(xc.shape).to(x_dt)
             else:
                 dx = GemmChain.run(torch.mm, dy2, wc).view(xc.shape).to(x_dt)
             if not ctx.needs_input_grad[1]:

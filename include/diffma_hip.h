@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 27
+#define DM_ABI_VERSION 28
 
 typedef enum {
     DM_OK = 0,
@@ -630,6 +630,17 @@ typedef struct {
 
 int dm_gemm(const dm_gemm_args *args, void *stream);
 int dm_gemm_supported(int P, int Q, int Kc, int a_kmajor, int b_kmajor, int ab_dtype, int c_dtype);
+
+/* ------------------------------------------------------------------------------------------------
+ * K12 (ABI 28)  dm_gemm_large -- the same product for the LARGE-BATCH projections (csrc/gemm_large.hip): both operands k-major,
+ * 16-bit C of the operand dtype, no accumulation.  Replaces the library (hipBLASLt through F.linear / torch.mm) GEMMs of
+ * in_proj / out_proj (reference block/mamba.py:261,315,333-337) and of their input gradients (through a transposed 16-bit copy
+ * of the weight) at M = B L >= 2048 rows: a persistent 256 x 256 tile kernel whose operand stream and C-tile stores run across
+ * tile boundaries (the contraction is only 512 .. 2048 long).  P >= 2048, Q % 256 == 0, Kc % 128 == 0; strides as dm_gemm,
+ * ldc % 8 == 0; every tensor below 2 GB.  dm_gemm_large_supported answers for a shape without launching.
+ * ---------------------------------------------------------------------------------------------- */
+int dm_gemm_large(const dm_gemm_args *args, void *stream);
+int dm_gemm_large_supported(int P, int Q, int Kc, int a_kmajor, int b_kmajor, int ab_dtype, int c_dtype);
 
 /* ------------------------------------------------------------------------------------------------
  * Several congruent launches in one (ABI 25).

@@ -1442,3 +1442,91 @@ def test_gemm_pair_is_bit_identical_to_two_launches(gpu):
     for k in (0, 1):
         for a, b in zip(ref[k], got[k]):
             assert torch.equal(a, b)
+
+
+# ---- K12: the persistent large-batch projection kernel (csrc/gemm_large.hip; reference block/mamba.py:261,315,333-337) ----------
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(100352, 2048, 512),      # in_proj forward at the bench batch: 392 row blocks x 8 = 12.25 rounds -> 12 + K11 tail
+                                   (100352, 512, 1024),       # out_proj forward: 3.06 rounds -> 3 + tail
+                                   (100352, 1024, 512),       # out_proj input gradient (transposed weight copy)
+                                   (100352, 512, 2048),       # in_proj input gradient
+                                   (34496, 2048, 512),        # batch 176 (the end-to-end test's size): 135 row blocks -> 128 + 7
+                                   (34419, 1024, 1024),       # ragged: the last row block has 115 rows (masked by the descriptors)
+                                   (2048, 256, 512)])         # the smallest it takes: 8 tiles, most workgroups idle
+def test_gemm_large_matches_fp64_matmul(gpu, dtype, M, N, K):
+    """C = A B^T by dm_gemm_large against the fp64 product of the same 16-bit operands (computed on the device: the fp64 library
+    GEMM is the checker here), every element of C: rel-L2 <= 1e-2 (bf16) / 2e-3 (fp16), and max |error| within 4 output ulps of
+    the largest entry (catches a single wrong tile, which a norm over 2 x 10^8 elements would not).  Then the same product with
+    strided operands -- A the x half of a wider row, C a column block of a wider buffer whose other columns must stay untouched."""
+    from diffma_amd import hip_ops
+
+    g = torch.Generator(device=gpu).manual_seed(M + N + K)
+    a = (torch.rand(M, K, device=gpu, generator=g) * 2 - 1).to(dtype)
+    b = ((torch.rand(N, K, device=gpu, generator=g) * 2 - 1) * K ** -0.5).to(dtype)
+    assert hip_ops.gemm_large_supported(a, b)
+    c = hip_ops.gemm_large(a, b)
+    ref = torch.empty(M, N, dtype=torch.float64, device=gpu)
+    for r0 in range(0, M, 16384):                                    # (fp64 temporaries of 16 k rows at a time)
+        ref[r0:r0 + 16384] = a[r0:r0 + 16384].double() @ b.double().t()
+    tol, ulp = (1e-2, 2.0 ** -8) if dtype == torch.bfloat16 else (2e-3, 2.0 ** -11)
+    err = (c.double() - ref)
+    assert float(err.norm() / ref.norm()) <= tol
+    assert float(err.abs().max()) <= 4 * ulp * float(ref.abs().max()), float(err.abs().max())
+    del err
+    # strided: A = columns [K, 2K) of a [M, 2K] buffer; C = columns [N, 2N) of a [M, 3N] buffer prefilled with a marker
+    wide = torch.empty(M, 2 * K, dtype=dtype, device=gpu)
+    wide[:, K:] = a
+    wide[:, :K] = 7.0
+    cbuf = torch.full((M, 3 * N), 5.0, dtype=dtype, device=gpu)
+    out = cbuf[:, N:2 * N]
+    assert hip_ops.gemm_large_supported(wide[:, K:], b, out)
+    hip_ops.gemm_large(wide[:, K:], b, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out, c)
+    assert float((cbuf[:, :N] - 5.0).abs().max()) == 0.0 and float((cbuf[:, 2 * N:] - 5.0).abs().max()) == 0.0
+
+
+def test_gemm_large_rejects_what_it_does_not_take(gpu):
+    """The predicate and the C entry agree: shapes outside the kernel's domain are refused with a status code, not launched."""
+    from diffma_amd import _lib, hip_ops
+
+    mk = lambda *s: torch.zeros(*s, dtype=torch.bfloat16, device=gpu)
+    assert not hip_ops.gemm_large_supported(mk(1024, 512), mk(2048, 512))        # fewer than 2048 rows
+    assert not hip_ops.gemm_large_supported(mk(4096, 512), mk(320, 512))         # columns not a multiple of 256
+    assert not hip_ops.gemm_large_supported(mk(4096, 384), mk(512, 384))         # contraction not a multiple of 512
+    assert not hip_ops.gemm_large_supported(mk(4096, 512).float(), mk(512, 512).float())
+    with pytest.raises(_lib.DiffmaHipError):
+        hip_ops.gemm_large(mk(4096, 384), mk(512, 384))
+
+
+@pytest.mark.parametrize("cols", [1024, 512])
+def test_linear_splitk_takes_the_large_kernel_and_matches_autograd(gpu, monkeypatch, cols):
+    """linear_splitk at the bench's row count: the forward and the input gradient run on K12 (the latter through the transposed
+    weight copy), the weight gradient on the split-K product -- all three against fp64 autograd of the same 16-bit operands."""
+    from diffma_amd import _lib
+    from diffma_amd import selective_scan_interface as ssi
+
+    names = []
+    real = _lib.call
+    monkeypatch.setattr(_lib, "call", lambda n, a, st: (names.append(n), real(n, a, st))[1])
+    g = torch.Generator(device=gpu).manual_seed(3)
+    M = 16384
+    # the default policy of selective_scan_interface._own_large (outputs of 1024 columns and more): in_proj forward and out_proj input
+    # gradient on K12, the two 512-column products on the library's NT kernels; with DIFFMA_GEMM_LARGE_MIN_COLS=512 all but the
+    # in_proj input gradient (contraction 2048)
+    monkeypatch.setattr(ssi, "LARGE_MIN_COLS", cols)
+    for K, N, want in ((512, 2048, 1), (1024, 512, 1 if cols == 1024 else 2)):
+        x = (torch.randn(M, K, device=gpu, generator=g)).bfloat16().requires_grad_(True)
+        W = (torch.randn(N, K, device=gpu, generator=g) * K ** -0.5).requires_grad_(True)       # fp32 master
+        dy = torch.randn(M, N, device=gpu, generator=g).bfloat16()
+        names.clear()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = ssi.linear_splitk(x, W)
+        y.backward(dy)
+        assert names.count("dm_gemm_large") == want, names
+        x64, W64 = x.detach().double().requires_grad_(True), W.detach().bfloat16().double().requires_grad_(True)
+        y64 = x64 @ W64.t()
+        y64.backward(dy.double())
+        assert rel_l2(y.detach(), y64.detach()) <= 1e-2
+        assert rel_l2(x.grad, x64.grad) <= 1e-2
+        assert rel_l2(W.grad, W64.grad) <= 1e-2

@@ -1225,7 +1225,9 @@ def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
     assert names.count("dm_selective_scan_fwd") == nmix and names.count("dm_selective_scan_bwd") == nmix          # K1, K2
     assert names.count("dm_dtproj_softplus_fwd") == nmix and names.count("dm_dtproj_bwd") == nmix                 # K8, K8b
     assert "dm_gather_conv1d_fwd" not in names and "dm_gather_conv1d_bwd" not in names                            # not the unfused pair
-    assert not any(n == "dm_gemm" and max(a.P, a.Q) <= 3200 and a.Kc <= 3200 for n, a in log)                     # not the small-launch GEMM
+    assert "dm_gemm" not in names                                                                                 # not the small-launch GEMM
+    # the wide projections on K12 (csrc/gemm_large.hip): in_proj forward and the input gradient of out_proj of every mixer, M = B L rows
+    assert sum(1 for n, a in log if n == "dm_gemm_large" and a.P == B * L) >= 2 * nmix, names.count("dm_gemm_large")
     # split-K weight gradients over M = B L rows (in_proj, out_proj, the fusion MLP) and 3 B L rows (x_proj)
     assert sum(1 for m, _, _ in tn if m == B * L) >= 2 * nmix and sum(1 for m, _, _ in tn if m == 3 * B * L) == nmix, tn
 

@@ -6,13 +6,19 @@ R=$GRAFT_REPO_ROOT
 TAG=$1; LIKE=$2; shift; shift
 OUT=/tmp/pmc_$TAG; rm -rf $OUT; mkdir -p $OUT $R/gpurun_out
 i=0
+# PMC_ONE="<counters>": a single pass with these counters instead of the standard passes
+if [ -n "$PMC_ONE" ]; then
+  rocprofv3 --kernel-trace --pmc $PMC_ONE -d $OUT/p1 -o k -- "$@" > $OUT/p1.log 2>&1
+else
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_LDS" \
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
            "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT" \
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $SET -d $OUT/p$i -o k -- "$@" > $OUT/p$i.log 2>&1
 done
+fi
 python - <<PY
 import sqlite3, glob
 out = []
