@@ -579,7 +579,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 
 // lanes per channel: a whole channel per lane up to d_state 16 (two lanes per channel = 3 waves per SIMD measured +10 % at d_state 16,
 // profiles/r03_k2_experiments.txt), half of one at d_state 32
-template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : 1; };
+#ifndef DM_K2_SPLIT16
+#define DM_K2_SPLIT16 1       // developer A/B: lanes per channel at d_state 16 (2 = half a channel per lane, 3 waves per SIMD)
+#endif
+template <int N> struct bwd_split { static constexpr int value = (N >= 32) ? 2 : (N == 16 ? DM_K2_SPLIT16 : 1); };
 
 template <typename T, typename TBC, int N, bool HAS_Z, bool IDX>
 static void launch_bwd2(const dm_scan_bwd_args& a, hipStream_t st, dim3 grid) {
