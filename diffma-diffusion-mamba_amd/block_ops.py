@@ -65,6 +65,8 @@ class _LnModFn(torch.autograd.Function):
             kw, plain = dict(dx=rx, dx2=rx2, accumulate=True), False
         elif not has_x2 and rx is not None and rx.dtype == x.dtype and rx.is_contiguous():
             kw, plain = dict(dx_add=rx), False                          # residual: possibly shared -> read only
+        if has_mod:
+            kw["mod_dtype"] = shift.dtype
         dx, dx2, dshift, dscale, dgamma, dbeta = hip_ops.ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, ctx.eps, stats, dy1,
                                                                     dy2 if has_mask else None, **kw)
         if plain:                                     # odd cases (one alias unused, dtype mismatch): plain sums
@@ -76,11 +78,33 @@ class _LnModFn(torch.autograd.Function):
                 dshift.to(shift.dtype) if has_mod else None, dscale.to(scale.dtype) if has_mod else None, None, None, None, None)
 
 
+_MASK_ONCE = [None]
+
+
+def _mask_once(w, B, L, dtype):
+    """The soft mask as a contiguous [B, L] tensor in the modulation dtype: every block of the denoiser applies the SAME mask
+    (reference block/mamba_block.py:103), so it is reshaped and cast once per mask tensor instead of once per block (a cast launch
+    per block and step at the reference's batch).  Keyed on the tensor object and its version; held weakly."""
+    import weakref
+
+    ent = _MASK_ONCE[0]
+    grad = w.requires_grad and torch.is_grad_enabled()
+    # a copy made outside a stream capture must not be baked into a captured graph (it is freed when the next mask replaces it) and a
+    # copy made inside one lives in that graph's pool: the capture state is part of the key
+    cap = w.is_cuda and torch.cuda.is_current_stream_capturing()
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == dtype and ent[3].shape == (B, L) and ent[4] == cap and not grad:
+        return ent[3]
+    m = w.reshape(B, L).contiguous().to(dtype)
+    if not grad:
+        _MASK_ONCE[0] = (weakref.ref(w), w._version, dtype, m, cap)
+    return m
+
+
 def ln_modulate_mask(x, norm: torch.nn.LayerNorm, shift, scale, w, passthrough=False):
     """(modulate(LN(x), shift, scale), same * w) with outputs in the autocast dtype.  shift/scale: [B, C] views.
     passthrough: also returns x itself for the residual branch (see PASS-THROUGH above): (x_ssm, w_ssm, x_res)."""
     with torch.autocast(device_type="cuda", enabled=False):
-        return _LnModFn.apply(x, None, norm.weight, norm.bias, shift, scale, w.reshape(x.shape[0], x.shape[1]).contiguous().to(shift.dtype),
+        return _LnModFn.apply(x, None, norm.weight, norm.bias, shift, scale, _mask_once(w, x.shape[0], x.shape[1], shift.dtype),
                               norm.eps, _autocast_dtype_cached[0], passthrough)
 
 
@@ -104,7 +128,7 @@ class _BlendFn(torch.autograd.Function):
         xs, ws, a_row, gate = ctx.saved_tensors
         g = g.contiguous()
         dxs, dws, da, dgate = hip_ops.blend_bwd(g, xs, ws, a_row, gate)
-        return g, dxs, dws, da, dgate.to(gate.dtype)
+        return g, dxs, dws, da, dgate
 
 
 def blend_residual(x, xs, ws, a_row, gate):

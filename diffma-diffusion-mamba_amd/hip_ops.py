@@ -872,9 +872,11 @@ def ln_mod_fwd(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
     return y1, y2, stats
 
 
-def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=None, dx2=None, accumulate=False, dx_add=None):
+def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=None, dx2=None, accumulate=False, dx_add=None, mod_dtype=None):
     """Returns (dx, dx2, dshift, dscale, dgamma, dbeta); dx/dx2 may be given (accumulate=True adds into them); dx_add [B, L, C1]
-    (x's dtype, read-only): dx = computed + dx_add -- the gradient of x's other consumer, which may be shared and stays intact."""
+    (x's dtype, read-only): dx = computed + dx_add -- the gradient of x's other consumer, which may be shared and stays intact.
+    mod_dtype: dtype of the returned dshift / dscale (default fp32): the partial rows are summed INTO that dtype (fp32 accumulation
+    inside the reduction) instead of being summed and cast in two launches each -- the small-batch step is made of launches."""
     _require_gpu(x, dy1)
     a, Bsz, L, C1, C2 = _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, dy1.dtype)
     C = C1 + C2
@@ -899,6 +901,10 @@ def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=
     if scale is None and shift is None:       # no modulation (the LayerNorm of the fusion MLP): only d gamma / d beta are wanted -- one
         pg = colsum(part.view(Bsz * bpb, 4 * C), True).view(4, C)      # column sum over all partial rows instead of two reductions
         return dx, dx2, None, None, pg[2], pg[3]
+    if mod_dtype is not None and mod_dtype != torch.float32:
+        ds = part[:, :, :2].sum(1, dtype=mod_dtype)                    # [B, 2, C] in the consumer's dtype: one launch
+        pg = part[:, :, 2:].sum((0, 1))                                # [2, C] fp32
+        return dx, dx2, ds[:, 0], ds[:, 1], pg[0], pg[1]
     pb = part.sum(1)                          # [B, 4, C]
     dshift, dscale = pb[:, 0], pb[:, 1]
     pg = pb.sum(0)
@@ -926,7 +932,7 @@ def blend_fwd(x, xs, ws, a_row, gate):
 
 
 def blend_bwd(g, xs, ws, a_row, gate):
-    """Returns (dxs, dws, da [B,L,1], dgate [B,C] fp32)."""
+    """Returns (dxs, dws, da [B,L,1], dgate [B,C] in the dtype of gate: the partial rows are summed into it, fp32 accumulation)."""
     _require_gpu(g, xs, ws, a_row, gate)
     a, Bsz, L, C = _blend_args(g, xs, ws, a_row, gate)
     if xs.shape == ws.shape and xs.dtype == ws.dtype and xs.is_contiguous() and ws.is_contiguous():
@@ -939,7 +945,7 @@ def blend_bwd(g, xs, ws, a_row, gate):
     part = torch.empty((Bsz, bpb, C), dtype=torch.float32, device=g.device)
     a.g, a.dxs, a.dws, a.da, a.dgate_part = _ptr(g), _ptr(dxs), _ptr(dws), _ptr(da), _ptr(part)
     _launch("dm_blend_bwd", a, g, Bsz * L * C * (g.element_size() + 4 * xs.element_size()))
-    return dxs, dws, da, part.sum(1)
+    return dxs, dws, da, part.sum(1, dtype=gate.dtype)
 
 
 # ------------------------------------------------------------------------------------------------

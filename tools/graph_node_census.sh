@@ -19,7 +19,7 @@ d = $K2 - $K1
 rows = []
 for n in set(a) | set(b):
     ca, ta = a.get(n, (0, 0)); cb, tb = b.get(n, (0, 0))
-    rows.append(((cb - ca) / d, (tb - ta) / d / 1e3, ca, cb, n))
+    rows.append(((cb - ca) / d, (tb - ta) / d / 1e3, ca, cb, n))   # total_duration is in ns
 rows.sort(reverse=True)
 per_step = sum(r[0] for r in rows)
 us = sum(r[1] for r in rows)
