@@ -524,7 +524,48 @@ constexpr int XS_SLOTS = ((XS_MAXL / XS_NW + 3 + XP_TM - 1) / XP_TM) * XP_TM;   
 // table read returns (op_sel_hi).  With acc_off first the compiler broadcasts the HIGH dword (op_sel:[1,0], or a v_mov into the low
 // register right in front of the v_pk_mul), and on MI355X that form gave the last 16 lanes a stale value for their first channel
 // now and then -- single rows missing from dw / db in a few channels (tools/dbg_k4x2.py; ROCm 7.2 hipcc).
+#ifndef DM_K4X_REPRO
+#define DM_K4X_REPRO 0       // developer: 1..5 rebuild the FAILING table layout with the multiply pinned in inline asm (tools/ubench/k4x_repro.sh)
+#endif
+#if DM_K4X_REPRO == 7        // control: the SHIPPED layout (own in the low dword) with the multiply pinned in inline asm as well
 struct xs_row { float own; uint32_t acc_off; };
+__device__ __forceinline__ f32x2 xs_mul_own_hi(const f32x2 gv, const f32x2 ent) {
+    f32x2 o;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(o) : "v"(gv), "v"(ent));
+    return o;
+}
+#elif DM_K4X_REPRO
+struct xs_row { uint32_t acc_off; float own; };
+// gv * own with own in the HIGH dword of the table pair: the instruction form hipcc chose for this layout, pinned, with the
+// candidates for a cure around it: 1 bare, 2 s_nop 7 behind it, 3 s_waitcnt lgkmcnt(0) in front of it, 4 s_nop 7 in front of it,
+// 5 the pair copied to a fresh register pair first (v_mov x2) and the multiply reading the copy
+__device__ __forceinline__ f32x2 xs_mul_own_hi(const f32x2 gv, const f32x2 ent) {
+    f32x2 o;
+#if DM_K4X_REPRO == 1
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(gv), "v"(ent));
+#elif DM_K4X_REPRO == 2
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]\n\ts_nop 7" : "=v"(o) : "v"(gv), "v"(ent));
+#elif DM_K4X_REPRO == 3
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(gv), "v"(ent));
+#elif DM_K4X_REPRO == 4
+    asm volatile("s_nop 7\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(gv), "v"(ent));
+#elif DM_K4X_REPRO == 8      // two plain multiplies by the high dword
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(o.x) : "v"(gv.x), "v"(ent.y));
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(o.y) : "v"(gv.y), "v"(ent.y));
+#elif DM_K4X_REPRO == 9      // early-clobber result: the destination pair shares no register with a source
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=&v"(o) : "v"(gv), "v"(ent));
+#elif DM_K4X_REPRO == 10     // sources swapped: own's pair as src0
+    asm volatile("v_pk_mul_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[1,1]" : "=&v"(o) : "v"(gv), "v"(ent));
+#else
+    f32x2 cp;
+    asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3\n\ts_nop 1" : "=&v"(cp.x), "=&v"(cp.y) : "v"(ent.x), "v"(ent.y));
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(o) : "v"(gv), "v"(cp));
+#endif
+    return o;
+}
+#else
+struct xs_row { float own; uint32_t acc_off; };
+#endif
 constexpr int XS_TOKP = XS_MAXL + 32;        // tokens of rows -3 .. L-1+, padded: a tile may start 3 rows early and end past the sequence
 
 template <typename T> struct xs_pair;      // the lane's two 16-bit channels <-> float2
@@ -701,7 +742,13 @@ __global__ __launch_bounds__(XS_THREADS, 1) void conv_xproj_bwd_slab_kernel(cons
                 const f32x2 sg = {fast_rcp(den.x), fast_rcp(den.y)};
                 const f32x2 fac = sg * (1.0f + pre * (1.0f - sg));                // silu'(pre)
                 gv[jj] = (pv + xs_pair<T>::up(cur.du[j])) * fac;
+#if DM_K4X_REPRO == 6                                                                 // the failing layout as hipcc compiles it
+                const f32x2 gvo = gv[jj] * rw[j].own;
+#elif DM_K4X_REPRO
+                const f32x2 gvo = xs_mul_own_hi(gv[jj], *reinterpret_cast<const f32x2*>(&rw[j]));
+#else
                 const f32x2 gvo = gv[jj] * rw[j].own;                             // rows after the segment are someone else's
+#endif
 #pragma unroll
                 for (int k = 0; k < W; ++k) dw[k] += gvo * xw[k];
                 db += gvo;

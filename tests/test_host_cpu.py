@@ -445,3 +445,47 @@ def test_slab_kernel_broadcasts_from_the_low_dword_only(tmp_path):
                 bad.append(line.strip())
     assert seen > 1000, "the slab kernel's packed arithmetic was not found in the object"
     assert not bad, f"low-from-high op_sel forms in the slab kernel: {bad[:3]}"
+
+
+def test_no_matrix_pipe_kernel_takes_a_packed_low_result_from_src1_high(tmp_path):
+    """Round 5 bisect of the K4x miscount (profiles/r05_k4x_repro.txt): inside a kernel that also issues MFMAs,
+    `v_pk_mul_f32 d, s0, s1 op_sel:[0,1]` -- the LOW result taking the HIGH dword of SRC1 -- gave lanes 48..63 a wrong low result in
+    every launch of the soak, whatever stood around it (s_nop 7 before or behind, s_waitcnt lgkmcnt(0), a fresh register copy of the
+    pair, an early-clobber destination); the same selection on SRC0, the low-dword broadcast and two plain multiplies are clean.
+    Kernels without MFMAs carry hundreds of these forms and pass every test.  So: no object of the library that contains v_mfma may
+    contain a packed fp32 instruction whose op_sel sets the src1 bit."""
+    import glob, re, subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    tools = [os.path.join(llvm, t) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")]
+    objs = sorted(glob.glob(os.path.join(ROOT, "diffma-diffusion-mamba_amd", "csrc", "*.o")))
+    if not objs or not all(os.path.isfile(t) for t in tools):
+        pytest.skip("needs the built objects and the ROCm llvm tools")
+    risky = re.compile(r"v_pk_(mul|add)_f32.*op_sel:\[[01],1\]|v_pk_fma_f32.*op_sel:\[[01],1,[01]\]")
+    checked, bad = 0, {}
+    for obj in objs:
+        fat, co = str(tmp_path / "x.fat"), str(tmp_path / "x.co")
+        if subprocess.run([tools[0], f"--dump-section=.hip_fatbin={fat}", obj], capture_output=True).returncode != 0 or not os.path.isfile(fat):
+            continue                                                    # host-only object
+        subprocess.run([tools[1], "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True)
+        dis = subprocess.run([tools[2], "-d", co], check=True, capture_output=True, text=True).stdout
+        os.remove(fat)
+        name, per = None, {}
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+            if m:
+                name = m.group(1)
+                per[name] = [0, []]
+                continue
+            if name is None:
+                continue
+            if "v_mfma" in line:
+                per[name][0] += 1
+            elif risky.search(line):
+                per[name][1].append(line.strip()[:90])
+        for k, (nm, lines) in per.items():
+            if nm:
+                checked += 1
+                if lines:
+                    bad[k[:80]] = lines[:2]
+    assert checked >= 20, f"only {checked} MFMA kernels found in the objects"
+    assert not bad, bad

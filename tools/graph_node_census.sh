@@ -19,15 +19,15 @@ d = $K2 - $K1
 rows = []
 for n in set(a) | set(b):
     ca, ta = a.get(n, (0, 0)); cb, tb = b.get(n, (0, 0))
-    rows.append(((cb - ca) / d, (tb - ta) / d / 1e3, ca, cb, n))   # total_duration is in ns
+    rows.append(((cb - ca) / d, (tb - ta) / d / 1e3, ca, cb, n))   # the view's durations are microseconds: ms per step
 rows.sort(reverse=True)
 per_step = sum(r[0] for r in rows)
 us = sum(r[1] for r in rows)
 out = [f"DiffMa-L/2 graphed training step, batch $B: kernel launches per replayed step = (trace of $K2 steps - trace of $K1 steps) / {d}",
-       f"total {per_step:.1f} launches and {us:.0f} us of kernel time per step", ""]
+       f"total {per_step:.1f} launches and {us:.2f} ms of kernel time per step", ""]
 for r in rows:
     if abs(r[0]) >= 0.05:
-        out.append(f"{r[0]:8.1f} /step {r[1]:9.1f} us/step   (calls {r[2]} -> {r[3]})  {r[4][:110]}")
+        out.append(f"{r[0]:8.1f} /step {r[1]:8.3f} ms/step   (calls {r[2]} -> {r[3]})  {r[4][:110]}")
 out.append("")
 out.append("launches that do NOT scale with the step count (set-up: warm-up steps, snapshot / restore of the training state, optimizer state):")
 for r in sorted(rows, key=lambda r: -r[2]):
