@@ -36,6 +36,13 @@ for name, m, n, k in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)
     a = (torch.rand(m, k, generator=g, device=dev) * 2 - 1).bfloat16()
     b = (torch.rand(n, k, generator=g, device=dev) * 2 - 1).bfloat16()
+    fill = os.environ.get("FILL", "")        # operand data and the chip's power limit: "ones" / "zeros" / "small" (random integers -2..2)
+    if fill == "ones":
+        a.fill_(1.0); b.fill_(1.0)
+    elif fill == "zeros":
+        a.zero_(); b.zero_()
+    elif fill == "small":
+        a = torch.randint(-2, 3, (m, k), generator=g, device=dev).bfloat16(); b = torch.randint(-2, 3, (n, k), generator=g, device=dev).bfloat16()
     out = torch.empty(m, n, dtype=torch.bfloat16, device=dev)
     ok = hip_ops.gemm_large_supported(a, b, out)
     t_lib = 1.0 if NOLIB else timeit(lambda: torch.nn.functional.linear(a, b))

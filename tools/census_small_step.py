@@ -44,7 +44,7 @@ import traceback  # noqa: E402
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WATCH = ("copy_", "fill_", "zero_", "zeros", "zeros_like", "clone", "_to_copy", "new_zeros", "full", "ones_like", "empty_like")
+WATCH = ("copy_", "fill_", "zero_", "zeros", "zeros_like", "clone", "_to_copy", "new_zeros", "full", "ones_like", "empty_like", "add", "add_", "sum", "cat", "mul", "index", "neg", "exp")
 by = collections.Counter()
 
 
