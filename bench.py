@@ -308,15 +308,48 @@ def gemm_accounting(step, steps_time_ms):
 
 def install_route_a():
     """--route-a: the mixers call the operator the way the REFERENCE's Mamba.forward does after the three-line import swap of
-    INTEGRATION.md section A (reference block/mamba.py:333-355): channel-major xz (B, 2*Din, L) from in_proj, CrossScan as two
-    gathers along L, THREE mamba_inner_fn calls (one per direction, each with its own conv / x_proj / dt_proj / scan / out_proj),
-    CrossMerge as row gathers of the three projected outputs.  What a reference user gets from the drop-in before touching
-    anything else; the native path (one fused 3-direction operator, token-major, merge before out_proj) is `Mamba.forward`."""
+    INTEGRATION.md section A (reference block/mamba.py:333-355): channel-major xz (B, 2*Din, L) from in_proj (a permuted VIEW of the
+    (2*Din, B*L) product), CrossScan into one (B, 3, 2*Din, L) buffer (two gathers along L; its backward gathers with the inverse
+    lists, block/mamba.py:31-57), THREE mamba_inner_fn calls on the buffer's strided slices (each with its own conv / x_proj /
+    dt_proj / scan / out_proj), the three outputs copied into one (B, 3, L, d_model) buffer, CrossMerge (row gathers with the
+    inverse lists; backward = row gathers with the forward lists, block/mamba.py:59-82).  Everything outside mamba_inner_fn is the
+    reference's own torch glue and is restated here as torch code; what the drop-in controls is what happens INSIDE the operator.
+    The native path (one fused 3-direction operator, token-major, merge before out_proj) is `Mamba.forward`."""
     from diffma_amd import selective_scan_interface as ssi
     from diffma_amd.mamba import Mamba
     from diffma_amd.selective_scan_interface import mamba_inner_fn
 
     ssi.PAIR_MIXERS = False            # the paired path is part of the native mixer, not of the reference's call pattern
+
+    class _Scan3(torch.autograd.Function):       # the reference's CrossScan: gathers along the LAST axis of (B, C, L)
+        @staticmethod
+        def forward(ctx, x, order, order_rev, orig, orig_rev):
+            ctx.inv = (orig, orig_rev)
+            xs = x.new_empty((x.shape[0], 3) + tuple(x.shape[1:]))
+            xs[:, 0] = x
+            xs[:, 1] = x[:, :, order]
+            xs[:, 2] = x[:, :, order_rev]
+            return xs
+
+        @staticmethod
+        def backward(ctx, g):
+            orig, orig_rev = ctx.inv
+            return g[:, 0] + g[:, 1][:, :, orig].contiguous() + g[:, 2][:, :, orig_rev].contiguous(), None, None, None, None
+
+    class _Merge3(torch.autograd.Function):      # the reference's CrossMerge: gathers along the ROW axis of (B, L, C)
+        @staticmethod
+        def forward(ctx, ys, order, order_rev, orig, orig_rev):
+            ctx.fwd = (order, order_rev)
+            return ys[:, 0] + ys[:, 1][:, orig, :].contiguous() + ys[:, 2][:, orig_rev, :].contiguous()
+
+        @staticmethod
+        def backward(ctx, g):
+            order, order_rev = ctx.fwd
+            gs = g.new_empty((g.shape[0], 3) + tuple(g.shape[1:]))
+            gs[:, 0] = g
+            gs[:, 1] = g[:, order, :]
+            gs[:, 2] = g[:, order_rev, :]
+            return gs, None, None, None, None
 
     def forward(self, hidden_states, scan_type="spiral", inference_params=None):
         assert scan_type == "spiral" and inference_params is None
@@ -325,15 +358,16 @@ def install_route_a():
         if idx is None or idx[0].device != hidden_states.device:
             mk = lambda l: torch.tensor(list(l), dtype=torch.long, device=hidden_states.device)
             idx = self._route_a_idx = (mk(self.token_list), mk(self.token_list_reversal), mk(self.origina_list), mk(self.origina_list_reversal))
-        order, order_rev, orig, orig_rev = idx
-        xz = (self.in_proj.weight @ hidden_states.reshape(Bsz * L, -1).t()).reshape(-1, Bsz, L).permute(1, 0, 2)     # (B, 2*Din, L), L contiguous
+        xz = (self.in_proj.weight @ hidden_states.reshape(Bsz * L, -1).t()).reshape(-1, Bsz, L).permute(1, 0, 2)     # (B, 2*Din, L) view, L contiguous
         A = -torch.exp(self.A_log.float())
-        outs = []
-        for sel in (None, order, order_rev):
-            xk = xz if sel is None else xz[:, :, sel].contiguous()
-            outs.append(mamba_inner_fn(xk, self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, self.out_proj.weight,
-                                       self.out_proj.bias, A, None, None, self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True))
-        return outs[0] + outs[1][:, orig, :] + outs[2][:, orig_rev, :]
+        xz_list = _Scan3.apply(xz, *idx)
+        outs = [mamba_inner_fn(xz_list[:, k], self.conv1d.weight, self.conv1d.bias, self.x_proj.weight, self.dt_proj.weight, self.out_proj.weight,
+                               self.out_proj.bias, A, None, None, self.D.float(), delta_bias=self.dt_proj.bias.float(), delta_softplus=True)
+                for k in range(3)]
+        out_m = outs[0].new_empty((Bsz, 3, L, outs[0].shape[-1]))
+        for k in range(3):
+            out_m[:, k] = outs[k]
+        return _Merge3.apply(out_m, *idx)
 
     Mamba.forward = forward
 

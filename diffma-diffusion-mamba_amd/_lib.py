@@ -101,6 +101,7 @@ dm_diffusion_step_args = _make_struct("dm_diffusion_step_args")
 dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
 dm_ssd_bwd_args = _make_struct("dm_ssd_bwd_args")
 dm_gemm_args = _make_struct("dm_gemm_args")
+dm_repack_args = _make_struct("dm_repack_args")
 
 _lib = None
 _lock = threading.Lock()

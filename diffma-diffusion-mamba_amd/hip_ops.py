@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_PARTIAL_COMPACT, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args, dm_repack_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -662,6 +662,34 @@ def token_merge(slabs, *, row_index=None, out=None, out_dtype=None, gate=None, p
     a.o_sb, a.o_sl = out.stride()[:2]
     extra = (0 if gate is None else 1) + (0 if pre_out is None else 1)
     _launch("dm_token_merge", a, slabs, ((K + extra) * slabs.element_size() + out.element_size()) * Bsz * L * Dm)
+    return out
+
+
+def repack(src, to_token_major, out=None):
+    """The operator boundary's layout change as one HBM-bound pass (csrc/repack.hip).
+    to_token_major=True : src (B, D, L) with stride(-1) == 1 (any batch / channel strides: CrossScan slices) -> [B, L, D] token-major;
+    to_token_major=False: src [B, L, D] with stride(-1) == 1                                          -> (B, D, L) contiguous."""
+    _require_gpu(src)
+    assert src.dim() == 3 and src.stride(2) == 1
+    a = dm_repack_args()
+    if to_token_major:
+        Bsz, Dm, L = src.shape
+        if out is None:
+            out = torch.empty((Bsz, L, Dm), dtype=src.dtype, device=src.device)
+        cm, tm = src, out
+    else:
+        Bsz, L, Dm = src.shape
+        if out is None:
+            out = torch.empty((Bsz, Dm, L), dtype=src.dtype, device=src.device)
+        cm, tm = out, src
+    assert out.stride(2) == 1 and out.dtype == src.dtype and cm.shape == (Bsz, Dm, L) and tm.shape == (Bsz, L, Dm)
+    a.batch, a.dim, a.seqlen = Bsz, Dm, L
+    a.io_dtype = dtype_code(src)
+    a.to_token_major = 1 if to_token_major else 0
+    a.src, a.dst = _ptr(src), _ptr(out)
+    a.cm_sb, a.cm_sd = cm.stride()[:2]
+    a.tm_sb, a.tm_sl = tm.stride()[:2]
+    _launch("dm_repack", a, src, 2 * Bsz * L * Dm * src.element_size())
     return out
 
 

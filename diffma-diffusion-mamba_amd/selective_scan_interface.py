@@ -23,10 +23,42 @@ from . import hip_ops
 from .step_prep import cast_weight, stacked_pair
 
 
+REPACK_OWN = os.environ.get("DIFFMA_REPACK_OWN", "1") == "1"        # 0: the ATen strided copy again (A/B runs)
+
+
 def _to_token_major(t: torch.Tensor) -> torch.Tensor:
-    """(B, D, L) in any layout -> a [B, L, D] tensor with stride(-1) == 1 (no copy when possible)."""
+    """(B, D, L) in any layout -> a [B, L, D] tensor with stride(-1) == 1 (no copy when possible; a genuinely L-contiguous
+    tensor -- what the reference hands over, block/mamba.py:333-348 -- goes through dm_repack).  No autograd: callers are
+    autograd Functions' forward / backward bodies; `_RepackFn` is the differentiable form."""
     tm = t.transpose(1, 2)
-    return tm if tm.stride(-1) == 1 else tm.contiguous()
+    if tm.stride(-1) == 1:
+        return tm
+    if REPACK_OWN and t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        return hip_ops.repack(t, True)
+    return tm.contiguous()
+
+
+def _to_channel_major(t: torch.Tensor) -> torch.Tensor:
+    """[B, L, D] token-major -> a CONTIGUOUS (B, D, L) tensor (the layout the reference's glue goes on with: CrossScan.backward,
+    the in_proj gradient products, block/mamba.py:47-57, 333-337); a lazily transposed view would make every consumer a
+    strided ATen copy."""
+    if REPACK_OWN and t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        return hip_ops.repack(t, False)
+    return t.transpose(1, 2).contiguous()
+
+
+class _RepackFn(torch.autograd.Function):
+    """(B, D, L) channel-major -> [B, L, D] token-major with the gradient handed back channel-major and contiguous."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return _to_token_major(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g.stride(-1) != 1:
+            g = g.contiguous()
+        return _to_channel_major(g)
 
 
 def _bc_token_major(Bm: torch.Tensor):
@@ -338,7 +370,9 @@ class _SpiralSSMFn(torch.autograd.Function):
         # 66-68), so merged[t] = silu(z[t]) * sum_k y~_k[t]: the scans run WITHOUT z and the gate is applied once per token by the
         # merge (one z read in an HBM-bound kernel) instead of three times inside the VALU-bound scans.  Needs the scatter table
         # to be the gather table (not ViM's) and a merge to ride on.
-        hoist = HOIST_GATE and merge and out_index is None and ndir > 1
+        # One direction (the reference's own three-calls-per-mixer pattern through mamba_inner_fn, the ZigMa order): the gate pass is an
+        # extra launch, worth it only where the scans are VALU-bound -- the large launches (K2 1 058 -> ~830 us per 512 sequences).
+        hoist = HOIST_GATE and merge and out_index is None and (ndir > 1 or Bsz >= hip_ops.XPROJ_FUSED_MIN_SEQS)
         # Hoisted softplus: delta = softplus(dt_proj(.) + bias) leaves the dt_proj kernel activated (csrc/dtproj.hip) and the scans
         # run with DM_FLAG_DELTA_ACTIVATED (forward: nothing to evaluate; backward: only 1 - exp(-delta)).
         # The backward of that flag exists for d_state 16 only (csrc/scan_bwd.hip): other widths keep the softplus inside the scans.
@@ -410,7 +444,7 @@ class _SpiralSSMFn(torch.autograd.Function):
         dWx = _tn_splitk(dx_dbl, xc.view(M, Din)).to(Wx.dtype)                   # [R+2N, Din]
         if hip_ops.conv_xproj_bwd_supported(xz[..., :Din], Wx_c, ndir * Bsz, conv_w.shape[-1], du, dx_dbl):
             # d x~ = du + dx_dbl @ Wx is formed tile by tile inside the conv backward (K4x) instead of by an addmm over [M, Din]
-            merged_dx = hip_ops.DX_MERGED and ndir > 1 and conv_w.shape[-1] == 4
+            merged_dx = hip_ops.DX_MERGED and conv_w.shape[-1] == 4         # one direction: dx straight into d(xz), no copy pass
             dx_slabs, dconv_w, dconv_b = hip_ops.gather_conv1d_xproj_bwd(xz[..., :Din], conv_w, conv_b, du, dx_dbl, Wx_c.t().contiguous(),
                                                                          row_index=scan_index, ndir=ndir, silu=True,
                                                                          merged_out=dxz[..., :Din] if merged_dx else None)
@@ -1035,7 +1069,8 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
         raise NotImplementedError("constant B/C and B/C projection biases are never used by DiffMa")
     if not delta_softplus:
         raise NotImplementedError("mamba_inner_fn is only defined with delta_softplus=True upstream")
-    xzt = _to_token_major(xz)                                                    # [B, L, 2Din]
+    # [B, L, 2Din]: a view when xz is a transposed token-major buffer, one dm_repack pass when it is the reference's L-contiguous slice
+    xzt = xz.transpose(1, 2) if xz.stride(1) == 1 else _RepackFn.apply(xz)
     ident = _const("ident", xzt.shape[1], xz.device)                              # made once per (length, device), not per call
     bias = delta_bias if delta_bias is not None else _const("zeros", xzt.shape[2] // 2, xz.device)
     Dsk = D if D is not None else _const("zeros", xzt.shape[2] // 2, xz.device)

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DM_ABI_VERSION 28
+#define DM_ABI_VERSION 29
 
 typedef enum {
     DM_OK = 0,
@@ -324,6 +324,30 @@ typedef struct {
 } dm_merge_args;
 
 int dm_token_merge(const dm_merge_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The operator boundary's layout change (ABI 29).  The reference calls its operators with CHANNEL-MAJOR tensors: xz is
+ * (B, 2 Din, L) with L contiguous -- block/mamba.py:333-337 builds it as a permuted view of the (2 Din, B L) in_proj product,
+ * CrossScan keeps the layout (block/mamba.py:31-45) and mamba_inner_fn / selective_scan_fn / causal_conv1d_fn take and return
+ * (B, D, L) (block/mamba.py:346-348).  The kernels above are token-major; dm_repack is the bridge, one HBM-bound pass
+ * (one read + one write of the tensor) in either direction:
+ *      to_token_major = 1:   tm[b][l][d] = cm[b][d][l]        src = cm, dst = tm
+ *      to_token_major = 0:   cm[b][d][l] = tm[b][l][d]        src = tm, dst = cm   (gradients back in the reference's layout)
+ * cm: element strides (cm_sb, cm_sd, 1); tm: (tm_sb, tm_sl, 1).  Any strides / alignment are accepted (16-byte, 8-byte or
+ * element accesses are chosen per side); elements are moved as words, so io_dtype only selects the width (DM_F32: 4 bytes,
+ * DM_BF16 / DM_F16: 2).  src and dst must not overlap.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, dim, seqlen;
+    int32_t io_dtype;
+    int32_t to_token_major;
+    const void *src;
+    void *dst;
+    int64_t cm_sb, cm_sd;
+    int64_t tm_sb, tm_sl;
+} dm_repack_args;
+
+int dm_repack(const dm_repack_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Backward of the hoisted gate  y = pre * silu(z):   g = dy * silu(z)   (what the per-direction scan backwards read as dout)

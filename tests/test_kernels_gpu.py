@@ -1530,3 +1530,86 @@ def test_linear_splitk_takes_the_large_kernel_and_matches_autograd(gpu, monkeypa
         assert rel_l2(y.detach(), y64.detach()) <= 1e-2
         assert rel_l2(x.grad, x64.grad) <= 1e-2
         assert rel_l2(W.grad, W64.grad) <= 1e-2
+
+
+# ---- K13 dm_repack: the operator boundary's layout change (channel-major (B, D, L) <-> token-major [B, L, D]) -- a move of words, bit-exact ----
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("Bsz,Dm,L,how", [
+    (3, 2048, 196, "crossscan"),      # the reference's call: slice k of a contiguous (B, 3, 2 Din, L) buffer (block/mamba.py:346-348): 8-byte runs along L
+    (2, 256, 64, "contiguous"),       # L % 8 == 0: 16-byte runs on both sides
+    (2, 200, 49, "contiguous"),       # odd L: element accesses along L, ragged channel tile (200 = 3 x 64 + 8)
+    (1, 100, 300, "contiguous"),      # two position tiles (256 + 44); dim % 8 != 0 -> element accesses on the token-major side
+    (2, 64, 7, "offset"),             # misaligned base pointer on the channel-major side
+    (1, 1, 1, "contiguous"),
+    (2, 130, 513, "padded"),          # three position tiles, padded rows on both sides
+])
+def test_repack_both_directions_bit_exact(gpu, dtype, Bsz, Dm, L, how):
+    from diffma_amd import hip_ops
+
+    g = torch.Generator().manual_seed(Bsz * 1000 + Dm + L)
+    if how == "crossscan":
+        base = torch.randn(Bsz, 3, Dm, L, generator=g).to(dtype).to(gpu)
+        cm = base[:, 1]
+    elif how == "offset":
+        base = torch.randn(Bsz * Dm * L + 3, generator=g).to(dtype).to(gpu)
+        cm = base[3:].view(Bsz, Dm, L)
+    elif how == "padded":
+        base = torch.randn(Bsz, Dm + 2, L + 5, generator=g).to(dtype).to(gpu)
+        cm = base[:, 1:Dm + 1, :L]
+    else:
+        cm = torch.randn(Bsz, Dm, L, generator=g).to(dtype).to(gpu)
+    tm = hip_ops.repack(cm, True)
+    assert tm.shape == (Bsz, L, Dm) and tm.is_contiguous()
+    assert torch.equal(tm, cm.transpose(1, 2).contiguous())
+    # and back, into a padded token-major source / strided channel-major destination
+    tsrc = torch.zeros(Bsz, L, Dm + (8 if how == "padded" else 0), dtype=dtype, device=gpu)[:, :, :Dm]
+    tsrc.copy_(tm)
+    back = hip_ops.repack(tsrc, False)
+    assert back.shape == (Bsz, Dm, L) and back.is_contiguous()
+    assert torch.equal(back, cm)
+    if how == "crossscan":             # written in place into a slice of the reference's (B, 3, C, L) buffer; the neighbours stay untouched
+        dst = torch.full((Bsz, 3, Dm, L), 7.0, dtype=dtype, device=gpu)
+        hip_ops.repack(tm, False, out=dst[:, 2])
+        assert torch.equal(dst[:, 2], cm) and bool((dst[:, :2] == 7.0).all())
+
+
+def test_repack_full_size_checksum(gpu):
+    """BASELINE size (batch 512 x 2048 channels x 196 tokens, bf16): a transpose is a permutation of words -- the sorted multiset of a
+    sample's words and per-channel sums survive it, and there-and-back is the identity."""
+    from diffma_amd import hip_ops
+
+    Bsz, Dm, L = 512, 2048, 196
+    xs = torch.empty(Bsz, 3, Dm, L, dtype=torch.bfloat16, device=gpu).normal_()
+    cm = xs[:, 2]
+    tm = hip_ops.repack(cm, True)
+    assert torch.equal(tm.view(torch.int16).sum(1, dtype=torch.int64), cm.view(torch.int16).sum(2, dtype=torch.int64))   # per (sample, channel) word sums, exact in int64
+    assert torch.equal(tm[17].reshape(-1).view(torch.int16).sort().values, cm[17].reshape(-1).view(torch.int16).sort().values)
+    assert torch.equal(hip_ops.repack(tm, False), cm)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_mamba_inner_fn_on_crossscan_slices_hands_back_channel_major_gradients(gpu, dtype):
+    """The reference's call pattern (block/mamba.py:343-348): three strided (B, 2 Din, L) slices of one buffer.  The operator's
+    result equals the one on a token-major copy (the layout change moves words), and the gradient arrives CONTIGUOUS in the
+    reference's layout (what CrossScan.backward and the in_proj products go on with)."""
+    from diffma_amd.selective_scan_interface import mamba_inner_fn
+
+    Bsz, Din, L, N, R, dmodel = 2, 128, 49, 16, 8, 64
+    g = torch.Generator().manual_seed(5)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).to(gpu)
+    xs = mk(Bsz, 3, 2 * Din, L).to(dtype).requires_grad_(True)
+    cw, cb = mk(Din, 1, 4, sc=0.5), mk(Din, sc=0.1)
+    xw, dtw, ow = mk(R + 2 * N, Din, sc=0.1), mk(Din, R, sc=0.3), mk(dmodel, Din, sc=0.1)
+    A, Dp, dtb = -(torch.rand(Din, N, generator=g) * 2 + 0.2).to(gpu), mk(Din), mk(Din, sc=0.3)
+    cast = (lambda t: t.to(dtype))
+    args = (cast(cw), cast(cb), cast(xw), cast(dtw), cast(ow), None, A, None, None, Dp)
+    outs = [mamba_inner_fn(xs[:, k], *args, delta_bias=dtb, delta_softplus=True) for k in range(3)]
+    go = mk(Bsz, L, dmodel).to(dtype)
+    (gx,) = torch.autograd.grad(outs, xs, [go, go * 0.5, go * 0.25])
+    # the same operator on token-major copies (transposed VIEWS: no repack on this path)
+    xt = xs.detach().permute(0, 1, 3, 2).contiguous().requires_grad_(True)          # (B, 3, L, 2 Din)
+    outs2 = [mamba_inner_fn(xt[:, k].transpose(1, 2), *args, delta_bias=dtb, delta_softplus=True) for k in range(3)]
+    (gt,) = torch.autograd.grad(outs2, xt, [go, go * 0.5, go * 0.25])
+    for a, b in zip(outs, outs2):
+        assert torch.equal(a, b)
+    assert torch.equal(gx, gt.permute(0, 1, 3, 2))

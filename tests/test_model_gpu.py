@@ -1253,3 +1253,55 @@ def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
     bad = {k: v for k, v in worst.items() if not v <= 6e-2}
     assert not bad, bad
     assert len(got) == sum(1 for k in sd64 if k != "pos_embed")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_mamba_inner_fn_reference_call_pattern_at_large_launch(gpu, dtype):
+    """INTEGRATION route A in the dispatch a large batch takes: mamba_inner_fn on a CrossScan slice with 512 sequences per call
+    (block/mamba.py:343-348) -- dm_repack in, the fused conv + x_proj kernels, ONE direction with the gate and the softplus hoisted
+    out of the sequential scans, dx / dz written straight into d(xz), dm_repack out -- forward and every gradient against fp64
+    autograd through the oracle's mamba_inner_ref."""
+    from diffma_amd import hip_ops
+    from diffma_amd.selective_scan_interface import mamba_inner_fn
+    from oracle.mamba_ref import mamba_inner_ref
+
+    gen = torch.Generator().manual_seed(11)
+    B, Din, L, N, R, dm = 512, 128, 28, 16, 16, 64
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc)
+    xs = mk(B, 3, 2 * Din, L).to(dtype)
+    cw, cb = mk(Din, 1, 4, sc=0.5), mk(Din, sc=0.1)
+    xw, dw, ow = mk(R + 2 * N, Din, sc=0.1).to(dtype), mk(Din, R, sc=0.3).to(dtype), mk(dm, Din, sc=0.1).to(dtype)
+    A, Dp, bias = -(torch.rand(Din, N, generator=gen) * 3 + 0.2), mk(Din), mk(Din, sc=0.3)
+    go = mk(B, L, dm).to(dtype)
+    names = "xs conv_w conv_b x_proj dt_proj out_proj A D dt_bias".split()
+    host = [xs, cw, cb, xw, dw, ow, A, Dp, bias]
+    dev = [t.to(gpu).requires_grad_(True) for t in host]
+    log = []
+    timer_was = hip_ops._TIMER
+
+    class _Log:
+        def launch(self, name, nbytes, fn, design_bytes=None, flops=0):
+            log.append(name)
+            fn()
+
+    hip_ops.set_timer(_Log())
+    try:
+        x_, cw_, cb_, xw_, dw_, ow_, A_, D_, b_ = dev
+        o = mamba_inner_fn(x_[:, 1], cw_, cb_, xw_, dw_, ow_, None, A_, None, None, D_, delta_bias=b_, delta_softplus=True)
+        (o.float() * go.to(gpu).float()).sum().backward()
+        torch.cuda.synchronize()
+    finally:
+        hip_ops.set_timer(timer_was)
+    assert log.count("dm_repack") == 2, log
+    if dtype == torch.bfloat16:          # the large-launch dispatch: fused conv + x_proj both ways, hoisted gate, no copy passes
+        assert "dm_gather_conv1d_xproj_fwd" in log and "dm_gather_conv1d_xproj_bwd" in log and "dm_gate_bwd" in log, log
+        assert log.count("dm_token_merge") == 1, log          # the gate pass of the forward; no dx / dz copy passes in the backward
+    ref = [t.double().requires_grad_(True) for t in host]
+    x_, cw_, cb_, xw_, dw_, ow_, A_, D_, b_ = ref
+    ro = mamba_inner_ref(x_[:, 1], cw_, cb_, xw_, dw_, ow_, None, A_, None, None, D_, delta_bias=b_, delta_softplus=True)
+    (ro * go.double()).sum().backward()
+    tol_o, tol_g = {torch.bfloat16: (1e-2, 3e-2), torch.float32: (1e-4, 5e-4)}[dtype]
+    assert rel_l2(o.detach().float().cpu(), ro.detach()) <= tol_o
+    assert float(dev[0].grad[:, 0].abs().max()) == 0.0 and float(dev[0].grad[:, 2].abs().max()) == 0.0      # the other slices get no gradient
+    for a, b, name in zip(dev, ref, names):
+        assert rel_l2(a.grad.float().cpu(), b.grad) <= tol_g, (name, rel_l2(a.grad.float().cpu(), b.grad))
