@@ -1075,4 +1075,6 @@ def mamba_inner_fn(xz, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_wei
     bias = delta_bias if delta_bias is not None else _const("zeros", xzt.shape[2] // 2, xz.device)
     Dsk = D if D is not None else _const("zeros", xzt.shape[2] // 2, xz.device)
     y = spiral_ssm(xzt, conv1d_weight, conv1d_bias, x_proj_weight, delta_proj_weight, bias, A, Dsk, ident)
-    return F.linear(y, out_proj_weight.to(y.dtype), out_proj_bias)
+    # out_proj the way the native mixer runs it: K11 / K12 / the tuned library by size, the input gradient as an NT product, the
+    # weight gradient split over the B L rows it contracts (F.linear's autograd hands those to untuned single-pass GEMMs)
+    return linear_splitk(y, out_proj_weight, out_proj_bias)

@@ -1266,7 +1266,7 @@ def test_mamba_inner_fn_reference_call_pattern_at_large_launch(gpu, dtype):
     from oracle.mamba_ref import mamba_inner_ref
 
     gen = torch.Generator().manual_seed(11)
-    B, Din, L, N, R, dm = 512, 128, 28, 16, 16, 64
+    B, Din, L, N, R, dm = 512, 128, 28, 16, 32, 64          # dt_rank 32: x_proj has the 64 rows the fused conv + x_proj backward is built for
     mk = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc)
     xs = mk(B, 3, 2 * Din, L).to(dtype)
     cw, cb = mk(Din, 1, 4, sc=0.5), mk(Din, sc=0.1)
