@@ -436,6 +436,25 @@ def colsum(x, small=False):
     if C % 4 != 0 or not x.is_contiguous() or x.dtype != torch.float32 or (small and not _COLSUM_SMALL):
         _pair_flush()
         return x.sum(0)
+    # The kernel gives every 256 columns ONE workgroup: a tall, narrow matrix (the conv backward's db partial rows at the Mamba-2 width:
+    # 5 376 x 2 560 = 10 workgroups) is then read by a handful of CUs.  Fold rb row classes into the columns -- x[R][C] read as
+    # [R / rb][rb C] is the same memory -- so that rb times as many workgroups stream it, and add the rb partial rows in a second,
+    # tiny launch.  The summation order stays fixed by the shape.
+    wgs = (C // 4 + 63) // 64
+    if COLSUM_SPLIT and R >= 256 and wgs < 48:
+        rb = 1
+        while rb < 32 and R % (2 * rb) == 0 and wgs * rb < 192 and R // (2 * rb) >= 16:
+            rb *= 2
+        if rb > 1:
+            return _colsum_launch(_colsum_launch(x.view(R // rb, rb * C)).view(rb, C))
+    return _colsum_launch(x)
+
+
+COLSUM_SPLIT = os.environ.get("DIFFMA_COLSUM_SPLIT", "1") == "1"        # 0: one workgroup per 256 columns whatever the shape (A/B runs)
+
+
+def _colsum_launch(x):
+    R, C = x.shape
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
     a = dm_colsum_args()
     a.rows, a.cols = R, C
