@@ -148,13 +148,19 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // gstride = 16 * (lanes in a row) every instruction reads / writes one dense run of 16-byte pieces.  (The lane-contiguous form,
 // 32 bytes per lane written by two instructions at a 32-byte lane stride, halves the instruction count as well but leaves every
 // 32-byte sector half-written per instruction: the forward scan got 7.5 % slower with it.)
+#ifndef DM_CK_ST_AUX
+#define DM_CK_ST_AUX 0         // cache-policy bits of the checkpoint stores / loads (developer A/B: 2 = nt, 1 = sc0, 16 = sc1)
+#endif
+#ifndef DM_CK_LD_AUX
+#define DM_CK_LD_AUX 0
+#endif
 template <int W>
 __device__ __forceinline__ void bio_st_words(const uint32_t (&w)[W], rsrc_t r, int voff, int soff, int gstride) {
     static_assert(W % 4 == 0, "whole 16-byte groups");
 #pragma unroll
     for (int g = 0; g < W / 4; ++g) {
         const u32x4_t q = {w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff + g * gstride, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, soff + g * gstride, DM_CK_ST_AUX);
     }
 }
 template <int W>
@@ -162,50 +168,56 @@ __device__ __forceinline__ void bio_ld_words(uint32_t (&w)[W], rsrc_t r, int vof
     static_assert(W % 4 == 0, "whole 16-byte groups");
 #pragma unroll
     for (int g = 0; g < W / 4; ++g) {
-        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + g * gstride, 0);
+        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff + g * gstride, DM_CK_LD_AUX);
         w[4 * g] = q[0]; w[4 * g + 1] = q[1]; w[4 * g + 2] = q[2]; w[4 * g + 3] = q[3];
     }
 }
+#ifndef DM_BIO_LD_AUX
+#define DM_BIO_LD_AUX 0        // cache-policy bits of the element loads / stores through bio<T> in this translation unit (2 = nt: streamed once)
+#endif
+#ifndef DM_BIO_ST_AUX
+#define DM_BIO_ST_AUX 0
+#endif
 template <typename T> struct bio;
 template <> struct bio<float> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
-        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, DM_BIO_LD_AUX));
     }
     // the loaded word as it is (a prefetched value must not be touched before its consumer: any arithmetic on it puts the
     // wait for the load right behind the load) and its conversion at the point of use
     typedef uint32_t raw_t;
-    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0); }
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, DM_BIO_LD_AUX); }
     static __device__ __forceinline__ float cv(raw_t w) { return __uint_as_float(w); }
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), r, voff, soff, DM_BIO_ST_AUX);
     }
     static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) { st(r, voff, soff, x); }
 };
 template <> struct bio<bf16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
-        return __uint_as_float(((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0)) << 16);
+        return __uint_as_float(((uint32_t)__builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, DM_BIO_LD_AUX)) << 16);
     }
     typedef unsigned short raw_t;
-    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, DM_BIO_LD_AUX); }
     static __device__ __forceinline__ float cv(raw_t w) { return __uint_as_float((uint32_t)w << 16); }
     static __device__ __forceinline__ void st(rsrc_t r, int voff, int soff, float x) {
         uint32_t b;
         asm("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(b) : "v"(x));       // low half is what store_b16 writes
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)b, r, voff, soff, DM_BIO_ST_AUX);
     }
     static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) {      // conversion visible to the scheduler
-        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)dm_cvt_pk_bf16(x, x), r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)dm_cvt_pk_bf16(x, x), r, voff, soff, DM_BIO_ST_AUX);
     }
 };
 template <> struct bio<f16_t> {
     static __device__ __forceinline__ float ld(rsrc_t r, int voff, int soff) {
-        const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0);
+        const unsigned short b = __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, DM_BIO_LD_AUX);
         _Float16 h;
         __builtin_memcpy(&h, &b, 2);
         return (float)h;
     }
     typedef unsigned short raw_t;
-    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, 0); }
+    static __device__ __forceinline__ raw_t ld_raw(rsrc_t r, int voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b16(r, voff, soff, DM_BIO_LD_AUX); }
     static __device__ __forceinline__ float cv(raw_t w) {
         const unsigned short b = w;
         _Float16 h;
@@ -216,7 +228,7 @@ template <> struct bio<f16_t> {
         const _Float16 h = (_Float16)x;
         unsigned short b;
         __builtin_memcpy(&b, &h, 2);
-        __builtin_amdgcn_raw_buffer_store_b16(b, r, voff, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b16(b, r, voff, soff, DM_BIO_ST_AUX);
     }
     static __device__ __forceinline__ void st_cv(rsrc_t r, int voff, int soff, float x) { st(r, voff, soff, x); }
 };

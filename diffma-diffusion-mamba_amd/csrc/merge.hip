@@ -8,11 +8,15 @@
 
 namespace dm {
 
+#ifndef DM_MERGE_NT
+#define DM_MERGE_NT 0          // 1: the streamed 16-byte accesses of merge / gate_bwd carry the nt hint (developer A/B)
+#endif
 // 16-byte (or narrower) vector move of VEC elements
 template <typename T, int VEC>
 __device__ __forceinline__ void vec_ld(T (&tmp)[VEC], const T* src) {
     if constexpr (VEC * sizeof(T) == 16) {
-        *(f32x4*)tmp = *(const f32x4*)src;
+        if (DM_MERGE_NT) *(f32x4*)tmp = __builtin_nontemporal_load((const f32x4*)src);
+        else *(f32x4*)tmp = *(const f32x4*)src;
     } else if constexpr (VEC * sizeof(T) == 8) {
         *(f32x2*)tmp = *(const f32x2*)src;
     } else {
@@ -23,7 +27,8 @@ __device__ __forceinline__ void vec_ld(T (&tmp)[VEC], const T* src) {
 template <typename T, int VEC>
 __device__ __forceinline__ void vec_st(T* dst, const T (&tmp)[VEC]) {
     if constexpr (VEC * sizeof(T) == 16) {
-        *(f32x4*)dst = *(const f32x4*)tmp;
+        if (DM_MERGE_NT) __builtin_nontemporal_store(*(const f32x4*)tmp, (f32x4*)dst);
+        else *(f32x4*)dst = *(const f32x4*)tmp;
     } else if constexpr (VEC * sizeof(T) == 8) {
         *(f32x2*)dst = *(const f32x2*)tmp;
     } else {
@@ -49,10 +54,8 @@ __global__ __launch_bounds__(256) void merge_kernel(const mix_args<dm_merge_args
         const int r = p.row_index ? p.row_index[(int64_t)k * p.seqlen + t] : t;
         const TI* src = (const TI*)p.in + (int64_t)k * p.in_sk + (int64_t)b * p.in_sb + (int64_t)r * p.in_sl + (int64_t)v * VEC;
         alignas(16) TI tmp[VEC];
-        if (VEC == 4 && sizeof(TI) == 4) {
-            *(f32x4*)tmp = *(const f32x4*)src;
-        } else if (VEC == 8 && sizeof(TI) == 2) {
-            *(f32x4*)tmp = *(const f32x4*)src;
+        if ((VEC == 4 && sizeof(TI) == 4) || (VEC == 8 && sizeof(TI) == 2)) {
+            vec_ld<TI, VEC>(tmp, src);
         } else {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) tmp[j] = src[j];
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void merge_kernel(const mix_args<dm_merge_args
     for (int j = 0; j < VEC; ++j) io<TO>::st(&outv[j], acc[j]);
     TO* dst = (TO*)p.out + (int64_t)b * p.o_sb + (int64_t)t * p.o_sl + (int64_t)v * VEC;
     if (VEC * sizeof(TO) == 16) {
-        *(f32x4*)dst = *(const f32x4*)outv;
+        vec_st<TO, VEC>(dst, outv);
     } else if (VEC * sizeof(TO) == 8) {
         *(f32x2*)dst = *(const f32x2*)outv;
     } else {

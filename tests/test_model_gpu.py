@@ -1305,3 +1305,50 @@ def test_mamba_inner_fn_reference_call_pattern_at_large_launch(gpu, dtype):
     assert float(dev[0].grad[:, 0].abs().max()) == 0.0 and float(dev[0].grad[:, 2].abs().max()) == 0.0      # the other slices get no gradient
     for a, b, name in zip(dev, ref, names):
         assert rel_l2(a.grad.float().cpu(), b.grad) <= tol_g, (name, rel_l2(a.grad.float().cpu(), b.grad))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_route_a_model_equals_native_model(gpu, dtype):
+    """INTEGRATION route A at model level: the reference's own Mamba.forward structure -- channel-major xz, CrossScan buffer, three
+    mamba_inner_fn calls on its strided slices, output buffer, CrossMerge (block/mamba.py:333-355), as bench.py --route-a restates
+    it -- gives the same training loss and the same parameter gradients as the native fused 3-direction mixer on the same weights
+    (fp32: <= 1e-4 / 1e-3; bf16 autocast: both are 16-bit evaluations of the same function, <= 2e-2 / 8e-2)."""
+    import bench
+    from diffma_amd import selective_scan_interface as ssi
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.mamba import Mamba
+    from diffma_amd.model import DiffMa
+
+    torch.manual_seed(21)
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16)
+    _rerandomize(net, 22)
+    net = net.to(gpu).train()
+    B, L = 3, 16
+    g = torch.Generator().manual_seed(23)
+    x, y, y2 = torch.randn(B, 4, 8, 8, generator=g).to(gpu), torch.randn(B, 64, generator=g).to(gpu), torch.randn(B, L, 64, generator=g).to(gpu)
+    w = torch.sigmoid(torch.randn(B, L, 1, generator=g)).to(gpu)
+    t = torch.randint(0, 1000, (B,), generator=g).to(gpu)
+    nz = torch.randn(B, 4, 8, 8, generator=g).to(gpu)
+    d = create_diffusion("")
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            loss = d.training_losses(net, x, t, dict(y=y, y2=y2, w=w), noise=nz)["loss"].mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}
+
+    loss_b, grads_b = run()
+    fwd, pair = Mamba.forward, ssi.PAIR_MIXERS
+    try:
+        bench.install_route_a()
+        assert Mamba.forward is not fwd
+        loss_a, grads_a = run()
+    finally:
+        Mamba.forward, ssi.PAIR_MIXERS = fwd, pair
+    tol_l, tol_g = {torch.float32: (1e-4, 1e-3), torch.bfloat16: (2e-2, 8e-2)}[dtype]
+    assert abs(loss_a - loss_b) <= tol_l * abs(loss_b), (loss_a, loss_b)
+    assert grads_a.keys() == grads_b.keys()
+    bad = {k: rel_l2(grads_a[k], grads_b[k]) for k in grads_b if float(grads_b[k].norm()) > 0 and not rel_l2(grads_a[k], grads_b[k]) <= tol_g}
+    assert not bad, bad
