@@ -132,10 +132,11 @@ __global__ __launch_bounds__(64 * LN_WAVES) void ln_mod_bwd_kernel(const dm_ln_m
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // keep the row arithmetic scalar
     const int C = p.C1 + p.C2;
-    const int bpb = (p.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
+    const int rpb = p.rows_per_block > 0 ? p.rows_per_block : DM_LN_ROWS_PER_BLOCK;
+    const int bpb = (p.rows_per_batch + rpb - 1) / rpb;
     const int b = blockIdx.x / bpb, blk = blockIdx.x - b * bpb;
-    const int row0 = blk * DM_LN_ROWS_PER_BLOCK;
-    const int row1 = min(row0 + DM_LN_ROWS_PER_BLOCK, p.rows_per_batch);
+    const int row0 = blk * rpb;
+    const int row1 = min(row0 + rpb, p.rows_per_batch);
     float g[NIT][VEC], be[NIT][VEC], sc[NIT][VEC];
     float a_sh[NIT][VEC], a_sc[NIT][VEC], a_g[NIT][VEC], a_b[NIT][VEC];
 #pragma unroll
@@ -264,10 +265,11 @@ template <typename TX, typename TS, typename TG, int VEC, int NIT>
 __global__ __launch_bounds__(64 * LN_WAVES) void blend_bwd_kernel(const dm_blend_args p) {
     __shared__ float lds[LN_WAVES][64 * LN_MAXE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bpb = (p.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
+    const int rpb = p.rows_per_block > 0 ? p.rows_per_block : DM_LN_ROWS_PER_BLOCK;
+    const int bpb = (p.rows_per_batch + rpb - 1) / rpb;
     const int b = blockIdx.x / bpb, blk = blockIdx.x - b * bpb;
-    const int row0 = blk * DM_LN_ROWS_PER_BLOCK;
-    const int row1 = min(row0 + DM_LN_ROWS_PER_BLOCK, p.rows_per_batch);
+    const int row0 = blk * rpb;
+    const int row1 = min(row0 + rpb, p.rows_per_batch);
     float gt[NIT][VEC], acc[NIT][VEC];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -371,7 +373,8 @@ static int ln_launch(const dm_ln_mod_args& a, hipStream_t st, bool bwd) {
         dim3 grid((unsigned)((rows + LN_WAVES - 1) / LN_WAVES));
         return pick_shape(C, vec_ok, DM_SHAPE_SWITCH(ln_mod_fwd_kernel, TX DM_COMMA TY DM_COMMA TM, grid, a), "dm_ln_mod_fwd");
     }
-    const int bpb = (a.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
+    const int rpb = a.rows_per_block > 0 ? a.rows_per_block : DM_LN_ROWS_PER_BLOCK;
+    const int bpb = (a.rows_per_batch + rpb - 1) / rpb;
     dim3 grid((unsigned)(a.batch * bpb));
     if (!a.scale && !a.mask && !a.dy2)
         return pick_shape(C, vec_ok, DM_SHAPE_SWITCH(ln_mod_bwd_kernel, TX DM_COMMA TY DM_COMMA no_mod_t, grid, a), "dm_ln_mod_bwd");
@@ -398,6 +401,7 @@ static int ln_entry(const dm_ln_mod_args* args, void* stream, bool bwd) {
     if (!bwd && (!a.y1 || (a.mask != nullptr) != (a.y2 != nullptr))) { set_error("%s: y1 required, y2 iff mask", who); return DM_ERR_ARG; }
     if (bwd && (!a.dy1 || !a.dx || !a.stats || !a.part || (a.C2 > 0 && !a.dx2) || (a.dy2 && !a.mask))) { set_error("%s: missing backward buffer", who); return DM_ERR_ARG; }
     if (bwd && a.dx_add && a.C2 > 0) { set_error("%s: dx_add is for the single-input form (C2 == 0)", who); return DM_ERR_ARG; }
+    if (bwd && (a.rows_per_block < 0 || a.rows_per_block % LN_WAVES)) { set_error("%s: rows_per_block must be 0 or a positive multiple of %d", who, LN_WAVES); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if (a.x_dtype == DM_F32 && a.y_dtype == DM_F32) rc = ln_by_mod<float, float>(a, st, bwd);
@@ -422,7 +426,8 @@ static int blend_launch(const dm_blend_args& a, hipStream_t st, bool bwd) {
         dim3 grid((unsigned)((rows + LN_WAVES - 1) / LN_WAVES));
         return pick_shape(a.C, vec_ok, DM_SHAPE_SWITCH(blend_fwd_kernel, TX DM_COMMA TS DM_COMMA TG, grid, a), "dm_blend_fwd");
     }
-    const int bpb = (a.rows_per_batch + DM_LN_ROWS_PER_BLOCK - 1) / DM_LN_ROWS_PER_BLOCK;
+    const int rpb = a.rows_per_block > 0 ? a.rows_per_block : DM_LN_ROWS_PER_BLOCK;
+    const int bpb = (a.rows_per_batch + rpb - 1) / rpb;
     dim3 grid((unsigned)(a.batch * bpb));
     return pick_shape(a.C, vec_ok, DM_SHAPE_SWITCH(blend_bwd_kernel, TX DM_COMMA TS DM_COMMA TG, grid, a), "dm_blend_bwd");
 }
@@ -435,6 +440,7 @@ static int blend_entry(const dm_blend_args* args, void* stream, bool bwd) {
     if (!bwd && (!a.x || !a.out)) { set_error("%s: x/out required", who); return DM_ERR_ARG; }
     if (bwd && (!a.g || !a.dxs || !a.dws || !a.da || !a.dgate_part)) { set_error("%s: missing backward buffer", who); return DM_ERR_ARG; }
     if (a.batch <= 0 || a.rows_per_batch <= 0 || a.C <= 0) { set_error("%s: non-positive size", who); return DM_ERR_ARG; }
+    if (bwd && (a.rows_per_block < 0 || a.rows_per_block % LN_WAVES)) { set_error("%s: rows_per_block must be 0 or a positive multiple of %d", who, LN_WAVES); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     int rc;
     const int key = a.x_dtype * 100 + a.s_dtype * 10 + a.g_dtype;

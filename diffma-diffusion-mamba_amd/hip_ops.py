@@ -882,6 +882,16 @@ def gemm_large(a, b, out=None):
 
 
 LN_ROWS_PER_BLOCK = 28   # DM_LN_ROWS_PER_BLOCK
+LN_SMALL_ROWS = int(os.environ.get("DIFFMA_LN_SMALL_ROWS", "4"))     # rows per partial-sum group of the backward when a launch has few rows; 0: always 28
+
+
+def _ln_rows_per_block(Bsz, L):
+    """Rows per workgroup (= per partial row) of dm_ln_mod_bwd / dm_blend_bwd.  A workgroup's 4 waves walk their rows one after the
+    other; with 28 rows a launch of few samples (the reference trains at ONE per GPU: 7 workgroups) is a chain of seven memory
+    latencies on 7 CUs.  Below one workgroup per CU: 4 rows (one per wave), 49 workgroups per sample at L = 196."""
+    if LN_SMALL_ROWS > 0 and Bsz * ((L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK) < 256:
+        return LN_SMALL_ROWS
+    return LN_ROWS_PER_BLOCK
 
 
 def _ln_args(x, x2, gamma, beta, shift, scale, mask, eps, y_dtype):
@@ -931,7 +941,8 @@ def ln_mod_bwd(x, x2, gamma, beta, shift, scale, mask, eps, stats, dy1, dy2, dx=
         dx = torch.empty((Bsz, L, C1), dtype=x.dtype, device=x.device)
     if x2 is not None and dx2 is None:
         dx2 = torch.empty((Bsz, L, C2), dtype=x2.dtype, device=x.device)
-    bpb = (L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK
+    a.rows_per_block = rpb = _ln_rows_per_block(Bsz, L)
+    bpb = (L + rpb - 1) // rpb
     part = torch.empty((Bsz, bpb, 4, C), dtype=torch.float32, device=x.device)
     a.stats, a.dy1, a.dy2, a.dx, a.dx2, a.part = _ptr(stats), _ptr(dy1), _ptr(dy2), _ptr(dx), _ptr(dx2), _ptr(part)
     a.dx_sr = dx.stride(1)
@@ -988,7 +999,8 @@ def blend_bwd(g, xs, ws, a_row, gate):
     else:
         dxs, dws = torch.empty_like(xs), torch.empty_like(ws)
     da = torch.empty_like(a_row)
-    bpb = (L + LN_ROWS_PER_BLOCK - 1) // LN_ROWS_PER_BLOCK
+    a.rows_per_block = rpb = _ln_rows_per_block(Bsz, L)
+    bpb = (L + rpb - 1) // rpb
     part = torch.empty((Bsz, bpb, C), dtype=torch.float32, device=g.device)
     a.g, a.dxs, a.dws, a.da, a.dgate_part = _ptr(g), _ptr(dxs), _ptr(dws), _ptr(da), _ptr(part)
     _launch("dm_blend_bwd", a, g, Bsz * L * C * (g.element_size() + 4 * xs.element_size()))

@@ -416,7 +416,9 @@ int dm_dtproj_bwd_supported(int dim, int rank, int io_dtype);
  *                  m = n * (1 + scale[b]) + shift[b]  (modulate, :8-9,104; skipped when scale == NULL),
  *                  y1 = m,  y2 = m * mask[row]  (soft mask, :105; skipped when mask == NULL).
  *                  stats[row] = {mean, rstd} (fp32) for the backward.  rows = batch * rows_per_batch.
- * dm_ln_mod_bwd :  given dy1 (, dy2): dx (, dx2), and fp32 partial sums over groups of DM_LN_ROWS_PER_BLOCK rows
+ * dm_ln_mod_bwd :  given dy1 (, dy2): dx (, dx2), and fp32 partial sums over groups of rows_per_block rows (a multiple of 4, one workgroup
+ *                  each; 0 = DM_LN_ROWS_PER_BLOCK.  Few samples per launch want small groups: at one sample 28-row groups are 7 workgroups
+ *                  whose waves walk 7 rows one after the other, 4-row groups are 49 workgroups of one row per wave)
  *                  part[blk][4][C] = {dshift, dscale, dgamma, dbeta}  (blk = b*blocks_per_batch + i);
  *                  accumulate != 0 adds into dx/dx2 instead of overwriting (the cat branch adds to the blend's
  *                  gradients); dx_add != NULL: dx = (computed) + dx_add[row] read-only (the residual branch's gradient,
@@ -431,7 +433,7 @@ typedef struct {
     int32_t x_dtype, y_dtype, mod_dtype;        /* x/x2/dx/dx2 ; y1/y2/dy1/dy2 ; shift/scale/mask           */
     int32_t accumulate;                         /* bwd only                                                  */
     float eps;
-    int32_t _pad;
+    int32_t rows_per_block;                     /* bwd only: rows per partial-sum group; 0 = DM_LN_ROWS_PER_BLOCK (ABI 29; this slot was padding) */
     const void *x, *x2;                         /* [rows][C1], [rows][C2], row strides below                 */
     const float *gamma, *beta;                  /* [C] or NULL (no affine)                                   */
     const void *shift, *scale;                  /* [batch][C] rows of stride mod_sb, or NULL                 */
@@ -452,6 +454,7 @@ int dm_ln_mod_bwd(const dm_ln_mod_args *args, void *stream);
 typedef struct {
     int32_t batch, rows_per_batch, C;
     int32_t x_dtype, s_dtype, g_dtype;          /* x/out/g ; xs/ws/dxs/dws/a/da ; gate                       */
+    int32_t rows_per_block, _pad;               /* bwd only: rows per partial-sum group; 0 = DM_LN_ROWS_PER_BLOCK (ABI 29)          */
     const void *x, *xs, *ws, *a, *gate;         /* gate [batch][C] rows of stride gate_sb; a [rows]          */
     void *out;                                  /* fwd                                                       */
     const void *g;                              /* bwd: dL/dout [rows][C]                                    */
