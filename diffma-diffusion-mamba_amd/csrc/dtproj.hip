@@ -91,7 +91,10 @@ __global__ __launch_bounds__(64 * DTP_WAVES) void dtproj_softplus_kernel(const m
         }
     }
 
-    const int tile0 = blockIdx.x * DTP_TILES;
+    // row tiles per workgroup: DTP_TILES for launches that fill the chip; a launch of few rows (the reference trains at ONE sample
+    // per GPU: 37 tiles per mixer) is spread over more workgroups instead of walking 8 tiles one after the other in 20 of them
+    const int tpw = (((p.rows + 15) >> 4) + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int tile0 = blockIdx.x * tpw;
     auto load_x = [&](int tile) -> dtp_u32x4 {
         int m = tile * 16 + j;
         m = (m < p.rows) ? m : p.rows - 1;
@@ -101,11 +104,11 @@ __global__ __launch_bounds__(64 * DTP_WAVES) void dtproj_softplus_kernel(const m
     };
     dtp_u32x4 xf = load_x(tile0);
 #pragma unroll 1
-    for (int tt = 0; tt < DTP_TILES; ++tt) {
+    for (int tt = 0; tt < tpw; ++tt) {
         const int tile = tile0 + tt;
         if (tile * 16 >= p.rows) break;                                        // wave-uniform
         const dtp_u32x4 xcur = xf;
-        if (tt + 1 < DTP_TILES) xf = load_x(tile + 1);                          // clamped rows: always a legal address
+        if (tt + 1 < tpw) xf = load_x(tile + 1);                                // clamped rows: always a legal address
 #pragma unroll
         for (int q = 0; q < DTP_NQ; ++q) {
             uint32_t pk[8];
@@ -162,6 +165,7 @@ extern "C" int dm_dtproj_softplus_fwd(const dm_dtproj_args* args, void* stream) 
     unsigned gz;
     const mix_args<dm_dtproj_args> m = mix_make(a, gz);
     dim3 grid((tiles + DTP_TILES - 1) / DTP_TILES, (a.dim + DTP_WAVES * DTP_NQ * 64 - 1) / (DTP_WAVES * DTP_NQ * 64), gz);
+    for (int tpw = DTP_TILES / 2; tpw >= 1 && grid.x * grid.y * gz < 512; tpw /= 2) grid.x = (tiles + tpw - 1) / tpw;     // fewer tiles per workgroup until the chip is covered twice
     if (grid.y > 65535) { set_error("dm_dtproj_softplus_fwd: dim too large"); return DM_ERR_ARG; }
     hipStream_t st = (hipStream_t)stream;
     if (a.io_dtype == DM_BF16) hipLaunchKernelGGL((dtproj_softplus_kernel<bf16_t>), grid, dim3(64 * DTP_WAVES), 0, st, m);
