@@ -30,7 +30,7 @@ DM_FLAG_DELTA_ACTIVATED = 128
 DM_FLAG_DX_MERGED = 256
 DM_FLAG_PARTIAL_COMPACT = 512
 
-_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float}
+_SCALARS = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 def _parse_structs(text: str):
@@ -102,6 +102,8 @@ dm_ssd_fwd_args = _make_struct("dm_ssd_fwd_args")
 dm_ssd_bwd_args = _make_struct("dm_ssd_bwd_args")
 dm_gemm_args = _make_struct("dm_gemm_args")
 dm_repack_args = _make_struct("dm_repack_args")
+dm_adamw_tensor = _make_struct("dm_adamw_tensor")
+dm_adamw_args = _make_struct("dm_adamw_args")
 
 _lib = None
 _lock = threading.Lock()

@@ -255,6 +255,17 @@ class GraphedTrainStep:
             if nst:
                 self.staged = StagedBackward(model, per=depth // nst)
         self._gp = [p for p in model.parameters() if p.requires_grad]
+        # AdamW + EMA in one pass over the parameters (csrc/optim.hip) on the optimizer's own state, when it is the plain AdamW the
+        # reference trains with (train.py:153-166); the parameters without a gradient keep their EMA through the multi-tensor lerp
+        from . import optim as _optim
+        self._fused = None
+        ema_of = {id(p): e for p, e in zip(self._mp, self._ep)} if ema is not None else None
+        if _optim.supported(optimizer, self._gp, [ema_of[id(p)] for p in self._gp] if ema_of else None):
+            self._fused = _optim.FusedAdamWEMA(optimizer, self._gp, [ema_of[id(p)] for p in self._gp] if ema_of else None,
+                                               ema_decay=ema_decay, ema_on_skip=True)
+            live = {id(p) for p in self._gp}
+            self._ep_rest = [e for p, e in zip(self._mp, self._ep) if id(p) not in live]
+            self._mp_rest = [p for p in self._mp if id(p) not in live]
         # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
         # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
         # gradients inside the graph and handed to the fused AdamW, which then leaves weights, moments and step count alone.
@@ -323,6 +334,13 @@ class GraphedTrainStep:
         return loss.detach()
 
     def _guarded_update(self, found):
+        if self._fused is not None and all(p.grad is not None for p in self._gp):
+            self._fused.step(found)                                   # weights, moments, counters and the EMA in one pass; found = 1 -> EMA only
+            with torch.no_grad():
+                self.skipped += found
+                if self._ep_rest:
+                    torch._foreach_lerp_(self._ep_rest, self._mp_rest, 1.0 - self.decay)
+            return
         self.opt.grad_scale, self.opt.found_inf = None, found          # read by the fused AdamW: found_inf = 1 -> no update
         self.opt.step()
         with torch.no_grad():

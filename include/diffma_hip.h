@@ -80,6 +80,41 @@ enum {
 };
 
 /* ------------------------------------------------------------------------------------------------
+ * The optimiser step of the training loop (ABI 29): AdamW + the EMA of the weights in ONE pass over the parameters.
+ * Reference: train.py:153-166 (`torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)`), train.py:259-264 (`opt.step()`,
+ * `update_ema(ema, model.module)`), train.py:36-47 (ema = decay * ema + (1 - decay) * param).  Arithmetic of torch's fused AdamW
+ * (decoupled weight decay, no amsgrad, no maximize), all tensors fp32:
+ *      p -= lr wd p;  m = beta1 m + (1 - beta1) g;  v = beta2 v + (1 - beta2) g g;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ *      (each expression in double, rounded to fp32 on assignment)
+ *      ema += (1 - ema_decay)(p - ema)                    (ema == NULL: no EMA for that tensor)
+ * `tensors` is a table in DEVICE memory, one entry per parameter; `step` points to the tensor's own step counter (a 0-dim fp32
+ * device tensor, torch's convention for fused / capturable optimisers): the call advances it by one and uses the new value as t.
+ * Work decomposition: workgroup i handles elements [block_chunk[i] * C, +C) of tensor block_tensor[i], C = dm_adamw_chunk(); the
+ * caller lists every chunk of every tensor once (two int32 device arrays of nblocks entries).  found_inf (device scalar or NULL):
+ * a non-zero value leaves p, m, v and the counters untouched; the EMA then still takes its step towards the unchanged weights if
+ * ema_on_skip != 0 and is left alone otherwise.  Two launches on `stream` (counters, then elements); graph-capturable.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    float *p, *m, *v;
+    const float *g;
+    float *ema;
+    float *step;
+    int64_t n;
+} dm_adamw_tensor;
+
+typedef struct {
+    const dm_adamw_tensor *tensors;
+    const int32_t *block_tensor, *block_chunk;
+    int32_t ntensors, nblocks;
+    double lr, beta1, beta2, eps, weight_decay, ema_decay;   /* double, as torch keeps them next to the fp32 elements */
+    const float *found_inf;
+    int32_t ema_on_skip, _pad;
+} dm_adamw_args;
+
+int dm_adamw_chunk(void);
+int dm_adamw_ema_step(const dm_adamw_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Selective scan, forward.   Replaces selective_scan_cuda.fwd behind
  *   selective_scan_fn(u, delta, A, B, C, D, z, delta_bias, delta_softplus)   (block/mamba.py:11)
  * and the scan stage of mamba_inner_fn (call sites block/mamba.py:346-348).

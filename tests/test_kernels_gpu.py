@@ -1619,3 +1619,54 @@ def test_mamba_inner_fn_on_crossscan_slices_hands_back_channel_major_gradients(g
     for a, b in zip(outs, outs2):
         assert torch.equal(a, b)
     assert torch.equal(gx, gt.permute(0, 1, 3, 2))
+
+
+# ---- K14 dm_adamw_ema_step: AdamW + EMA in one pass, on a torch.optim.AdamW instance's own state ----
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adamw_ema_matches_torch(gpu, wd):
+    """Reference step: train.py:153-166, 259-264 (AdamW lr 1e-4 wd 0, then update_ema).  Against torch's fused AdamW followed by
+    _foreach_lerp_ on identical copies: weights, both moments, the per-tensor step counters and the EMA after every one of 4 steps --
+    one of them dropped through found_inf (weights / moments / counters untouched, the EMA takes its step towards the unchanged
+    weights) -- for tensors of 1 element to several chunks, sizes that are not multiples of 4, and a misaligned view.  fp32 arithmetic
+    with the scalars in double as torch keeps them; bound: 8 ulp, and 5e-9 absolute on the weights (2 ulp of the lr-sized update a weight near zero is the difference of)."""
+    from diffma_amd import optim
+
+    g = torch.Generator().manual_seed(7)
+    shapes = [(1,), (3,), (5, 7), (1024,), (4097,), (64, 513), (3, 16384 + 1), (512, 2048)]
+    base = [torch.randn(*s, generator=g).to(gpu) for s in shapes]
+    odd = torch.randn(1031, generator=g).to(gpu)
+    def make():
+        ps = [torch.nn.Parameter(b.clone()) for b in base] + [torch.nn.Parameter(odd.clone()[1:1030])]
+        return ps
+    pa, pb = make(), make()
+    assert pa[-1].data_ptr() % 16 != 0
+    ea, eb = [p.detach().clone() * 0.5 for p in pa], [p.detach().clone() * 0.5 for p in pb]
+    kw = dict(lr=1e-2, weight_decay=wd, betas=(0.9, 0.999), eps=1e-8)
+    oa = torch.optim.AdamW(pa, fused=True, capturable=True, **kw)
+    ob = torch.optim.AdamW(pb, fused=True, capturable=True, **kw)
+    assert optim.supported(ob, pb, eb)
+    fused = optim.FusedAdamWEMA(ob, pb, eb, ema_decay=0.9, ema_on_skip=True)
+    for step in range(4):
+        grads = [torch.randn(p.shape, generator=g).to(gpu) * (10.0 ** (step - 2)) for p in pa]
+        skip = step == 2
+        found = torch.full((), 1.0 if skip else 0.0, device=gpu)
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad, q.grad = gr.clone(), (gr.clone() if not skip else torch.full_like(gr, float("nan")))
+        if not skip:
+            oa.step()
+        torch._foreach_lerp_(ea, [p.detach() for p in pa], 1.0 - 0.9)
+        fused.step(found)
+        torch.cuda.synchronize()
+        for i, (p, q) in enumerate(zip(pa, pb)):
+            sa, sb = oa.state[p], ob.state[q]
+            if len(sa) == 0:                      # torch has not stepped yet (first step skipped is not the case here)
+                continue
+            assert float(sa["step"]) == float(sb["step"]), (step, i)
+            torch.testing.assert_close(q.detach(), p.detach(), rtol=1e-6, atol=5e-9, msg=lambda m, i=i: f"step {step} weight {i}: {m}")
+            torch.testing.assert_close(sb["exp_avg"], sa["exp_avg"], rtol=1e-6, atol=1e-12, msg=lambda m, i=i: f"step {step} exp_avg {i}: {m}")
+            torch.testing.assert_close(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=1e-6, atol=1e-12, msg=lambda m, i=i: f"step {step} exp_avg_sq {i}: {m}")
+            torch.testing.assert_close(eb[i], ea[i], rtol=1e-6, atol=5e-9, msg=lambda m, i=i: f"step {step} ema {i}: {m}")
+    assert float(oa.state[pa[0]]["step"]) == 3.0
+    # the state is the optimizer's own: torch's step continues from it
+    sd = ob.state_dict()
+    assert len(sd["state"]) == len(pb) and float(sd["state"][0]["step"]) == 3.0
