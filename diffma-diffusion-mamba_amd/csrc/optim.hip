@@ -105,7 +105,43 @@ __global__ __launch_bounds__(AW_THREADS) void adamw_ema_kernel(const dm_adamw_ar
     }
 }
 
+// found[0] = 1 if any gradient element of the table is Inf / NaN (the caller zeroes it first): what
+// torch._amp_foreach_non_finite_check_and_unscale_ computes with 6 multi-tensor launches, as one
+__global__ __launch_bounds__(AW_THREADS) void grads_nonfinite_kernel(const dm_adamw_args p) {
+    const dm_adamw_tensor T = p.tensors[p.block_tensor[blockIdx.x]];
+    const int64_t base = (int64_t)p.block_chunk[blockIdx.x] * AW_CHUNK;
+    const bool vec = ((uintptr_t)T.g & 15) == 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < AW_VPT; ++k) {
+        const int64_t i0 = base + ((int64_t)k * AW_THREADS + threadIdx.x) * 4;
+        if (i0 >= T.n) break;
+        const int cnt = (int)((T.n - i0) < 4 ? (T.n - i0) : 4);
+        if (vec && cnt == 4) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(T.g + i0);
+            // x - x is 0 for every finite x and NaN for Inf / NaN
+            const float z = (g.x - g.x) + (g.y - g.y) + (g.z - g.z) + (g.w - g.w);
+            bad = bad || !(z == 0.0f);
+        } else {
+            for (int j = 0; j < cnt; ++j) { const float x = T.g[i0 + j]; bad = bad || !((x - x) == 0.0f); }
+        }
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) *p.nonfinite_out = 1.0f;
+}
+
 }  // namespace dm
+
+extern "C" int dm_grads_nonfinite(const dm_adamw_args* args, void* stream) {
+    using namespace dm;
+    if (!args) { set_error("dm_grads_nonfinite: null args"); return DM_ERR_ARG; }
+    const dm_adamw_args& a = *args;
+    if (!a.tensors || !a.block_tensor || !a.block_chunk || !a.nonfinite_out) { set_error("dm_grads_nonfinite: null table / output pointer"); return DM_ERR_ARG; }
+    if (a.ntensors <= 0 || a.nblocks <= 0) { set_error("dm_grads_nonfinite: non-positive ntensors / nblocks"); return DM_ERR_ARG; }
+    hipLaunchKernelGGL(grads_nonfinite_kernel, dim3(a.nblocks), dim3(AW_THREADS), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error("dm_grads_nonfinite: launch failed: %s", hipGetErrorString(e)); return DM_ERR_LAUNCH; }
+    return DM_OK;
+}
 
 extern "C" int dm_adamw_chunk(void) { return dm::AW_CHUNK; }
 

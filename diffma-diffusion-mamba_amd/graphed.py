@@ -327,7 +327,9 @@ class GraphedTrainStep:
         loss.backward()
         found = torch.zeros((), device=self.sz.device)            # 0-dim like GradScaler's (the fused AdamW subtracts it from its 0-dim step counters)
         grads = [p.grad for p in self._gp if p.grad is not None]
-        if grads:
+        if self._fused is not None and len(grads) == len(self._gp):
+            self._fused.nonfinite(found)                                                    # one launch over the optimiser's tensor table
+        elif grads:
             torch._amp_foreach_non_finite_check_and_unscale_(grads, found, self._one)      # inv_scale 1: a pure check
         self._guarded_update(found)
         self.opt.zero_grad(set_to_none=True)
@@ -397,12 +399,15 @@ class GraphedTrainStep:
                 groups = [(self._gp, self.flat)]
             found = None
             dst, src = [], []
+            in_place = self._fused is not None and all(f.dtype == torch.float32 for _, f in groups)
             for ps, flat in groups:
                 off = 0
                 for p in ps:                                # the averaged gradients back into the tensors the optimizer reads
                     n = p.numel()
                     g = flat[off:off + n].view_as(p)
-                    if p.grad is None:
+                    if in_place:                            # K14 reads the gradient through its table: the slice of the flat buffer IS the gradient
+                        p.grad = g
+                    elif p.grad is None:
                         p.grad = g.to(p.dtype).clone()
                     else:
                         dst.append(p.grad)

@@ -94,15 +94,35 @@ class FusedAdamWEMA:
             self._sizes = sizes
         self._key = key
 
-    @torch.no_grad()
-    def step(self, found_inf=None):
+    def _live(self):
         live = [i for i, p in enumerate(self.params) if p.grad is not None]
-        if not live:
-            return
         for i in live:
             g = self.params[i].grad
             if g.dtype != torch.float32 or not g.is_contiguous():
                 raise RuntimeError("FusedAdamWEMA needs fp32 contiguous gradients")
+        return live
+
+    @torch.no_grad()
+    def nonfinite(self, found):
+        """found (0-dim fp32 device tensor, zeroed by the caller) becomes 1 if any gradient holds an Inf / NaN: one launch over the table."""
+        live = self._live()
+        if not live:
+            return found
+        self._build(live)
+        a = dm_adamw_args()
+        a.tensors, a.block_tensor, a.block_chunk = self._table.data_ptr(), self._bt.data_ptr(), self._bc.data_ptr()
+        a.ntensors, a.nblocks = len(live), int(self._bt.numel())
+        a.nonfinite_out = found.data_ptr()
+        dev = self.params[0].device
+        with torch.cuda.device(dev):
+            _lib.call("dm_grads_nonfinite", a, torch.cuda.current_stream(dev).cuda_stream)
+        return found
+
+    @torch.no_grad()
+    def step(self, found_inf=None):
+        live = self._live()
+        if not live:
+            return
         self._build(live)
         grp = self.opt.param_groups[0]
         a = dm_adamw_args()

@@ -109,10 +109,14 @@ typedef struct {
     double lr, beta1, beta2, eps, weight_decay, ema_decay;   /* double, as torch keeps them next to the fp32 elements */
     const float *found_inf;
     int32_t ema_on_skip, _pad;
+    float *nonfinite_out;      /* dm_grads_nonfinite only */
 } dm_adamw_args;
 
 int dm_adamw_chunk(void);
 int dm_adamw_ema_step(const dm_adamw_args *args, void *stream);
+/* *nonfinite_out = 1 if any element of any gradient in the table is Inf / NaN (the caller zeroes it first; nothing else of `args` but the
+ * table and the block arrays is read): the device-side decision of the reference's `if not torch.isfinite(...)`: continue (train.py:254-256). */
+int dm_grads_nonfinite(const dm_adamw_args *args, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Selective scan, forward.   Replaces selective_scan_cuda.fwd behind
