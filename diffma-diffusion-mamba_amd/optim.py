@@ -10,7 +10,6 @@ reference's own configuration -- the optimiser and the EMA are a sixth of the tr
 """
 from __future__ import annotations
 
-import ctypes
 import os
 
 import torch

@@ -489,3 +489,21 @@ def test_no_matrix_pipe_kernel_takes_a_packed_low_result_from_src1_high(tmp_path
                     bad[k[:80]] = lines[:2]
     assert checked >= 20, f"only {checked} MFMA kernels found in the objects"
     assert not bad, bad
+
+
+def test_fused_optimizer_predicate_and_state_layout():
+    """optim.supported: only a plain one-group torch.optim.AdamW on fp32 ROCm tensors is taken (anything else keeps torch's own step);
+    the argument structs of the C ABI carry the scalars as doubles, as torch keeps them (include/diffma_hip.h)."""
+    import ctypes
+
+    from diffma_amd import _lib, optim
+
+    p = [torch.nn.Parameter(torch.randn(8, 4))]
+    assert not optim.supported(torch.optim.AdamW(p, lr=1e-4), p)                       # CPU tensors: no product path on the CPU
+    assert not optim.supported(torch.optim.SGD(p, lr=1e-4), p)
+    assert not optim.supported(torch.optim.AdamW(p, lr=1e-4, amsgrad=True), p)
+    fields = dict(_lib.STRUCT_FIELDS["dm_adamw_args"])
+    for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "ema_decay"):
+        assert fields[k] is ctypes.c_double, k
+    assert [f for f, _ in _lib.STRUCT_FIELDS["dm_adamw_tensor"]] == ["p", "m", "v", "g", "ema", "step", "n"]
+    assert ctypes.sizeof(_lib.dm_adamw_tensor) == 56                                   # 7 x 8 bytes: the rows FusedAdamWEMA writes as int64
