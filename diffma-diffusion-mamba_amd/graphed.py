@@ -124,6 +124,7 @@ class StagedBackward:
 
     # ---- forward-side cuts ------------------------------------------------------------------------------------------------
     def __enter__(self):
+        self.model._no_adaln_all = True            # the cuts below re-route `c` per block: each block runs its own adaLN product
         self.orig, self.leaf = [None] * self.depth, [None] * self.depth
         self.c_orig = self.c_leaf = self.x0_orig = self.x0_leaf = None
         cut = lambda t: t.detach().requires_grad_(True)
@@ -154,6 +155,7 @@ class StagedBackward:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        self.model._no_adaln_all = False
         return False
 
     def _reads(self, i):

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import block_ops, hip_ops
 from .mamba import Mamba, forward_pair
-from .selective_scan_interface import GemmChain, linear_splitk
+from .selective_scan_interface import GemmChain, _mm_f32, linear_splitk
 
 
 _SILU_ONCE = [None]
@@ -41,6 +41,58 @@ def _silu_once(c, dtype):
     # after which a later call with the same tensor recomputes instead of handing out a result whose graph has been freed.
     _SILU_ONCE[0] = (weakref.ref(c), c._version, dtype, grad, weakref.ref(out) if grad else out)
     return out
+
+
+class _AdaLNAllFn(torch.autograd.Function):
+    """The adaLN Linear of EVERY block in one product.  All blocks modulate with the same SiLU(c) (reference block/mamba_block.py:
+    82-85, 101; model.py:286-295 passes one `c` down the stack), so their 16 products [B, 2 D] x [2 D, 3 D] are one product with the
+    stacked weight [16 * 3 D, 2 D] -- which exists without a copy: step_prep keeps the blocks' 16-bit weight copies as the rows of one
+    buffer.  Forward: one GEMM; backward: the blocks' gradients concatenated, one product for d SiLU(c), one for all weight gradients
+    (handed back as row views), one column sum for the biases: 5 launches where the per-block form has 4 per block."""
+
+    @staticmethod
+    def forward(ctx, sc, wbase, bbase, *masters):
+        nb, N, K = wbase.shape
+        out = torch.addmm(bbase.view(-1), sc, wbase.view(nb * N, K).t())          # [B, nb * N]
+        ctx.save_for_backward(sc, wbase)
+        ctx.nb, ctx.N = nb, N
+        ctx.dtypes = [m.dtype for m in masters]
+        return tuple(out[:, i * N:(i + 1) * N] for i in range(nb))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        sc, wbase = ctx.saved_tensors
+        nb, N = ctx.nb, ctx.N
+        K = wbase.shape[-1]
+        gs = [g if g is not None else sc.new_zeros((sc.shape[0], N)) for g in grads]
+        g_all = torch.cat([g.to(sc.dtype) for g in gs], dim=1)                   # [B, nb * N]
+        with torch.autocast(device_type=sc.device.type, enabled=False):
+            d_sc = g_all @ wbase.view(nb * N, K) if ctx.needs_input_grad[0] else None
+            dW = _mm_f32(g_all.t(), sc).view(nb, N, K)                             # fp32 [nb, N, K]
+            db = g_all.sum(0, dtype=torch.float32).view(nb, N)
+        dws = [dW[i].to(ctx.dtypes[i]) for i in range(nb)]
+        dbs = [db[i].to(ctx.dtypes[nb + i]) for i in range(nb)]
+        return (d_sc, None, None, *dws, *dbs)
+
+
+def adaln_all(model, c):
+    """Per-block (shift, scale, gate) triples for the whole stack from one product, or None when the stacked 16-bit weights are not
+    current (no prepare() this step: inference, CPU, a weight written since) -- the blocks then run their own adaLN as before."""
+    from . import step_prep
+
+    if not (c.is_cuda and torch.is_grad_enabled() and ADALN_ALL) or getattr(model, "_no_adaln_all", False):
+        return None
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else c.dtype
+    if act not in (torch.bfloat16, torch.float16):
+        return None
+    st, pr = step_prep.adaln_stack(model, act), step_prep.adaln_params(model)
+    if st is None or pr is None or len(pr[0]) != len(model.blocks):
+        return None
+    outs = _AdaLNAllFn.apply(_silu_once(c, act), st[0], st[1], *pr[0], *pr[1])
+    return [o.chunk(3, dim=1) for o in outs]
+
+
+ADALN_ALL = os.environ.get("DIFFMA_ADALN_ALL", "1") == "1"        # 0: one adaLN product per block again (A/B runs)
 
 
 def modulate(x, shift, scale):
@@ -133,8 +185,10 @@ class Spiral_MambaBlock(nn.Module):
         w_ssm.record_stream(main)                 # allocated on `side`, read on `main`
         return x_ssm, w_ssm
 
-    def forward(self, x, c, w):
-        if self.fused_elementwise and x.is_cuda:
+    def forward(self, x, c, w, mod=None):
+        if mod is not None:                       # (shift, scale, gate) of this block from the stack-wide product (adaln_all)
+            shift, scale, gate = mod
+        elif self.fused_elementwise and x.is_cuda:
             # adaLN through linear_splitk: its 16-bit weight / bias copies come from the step's foreach cast (step_prep) instead of two
             # cast launches per block, and the weight gradient leaves its GEMM in fp32
             ada = self.adaLN_modulation

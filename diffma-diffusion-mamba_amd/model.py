@@ -160,14 +160,19 @@ class DiffMa(nn.Module):
         x = self.x_embedder(x) + self.pos_embed
         t = self.t_embedder(t)
         c = torch.cat((t + y, t + y2.mean(dim=1)), dim=1)
+        mods = None
+        if x.is_cuda and torch.is_grad_enabled() and self.block_type == "spiral":
+            from .mamba_block import adaln_all
+            mods = adaln_all(self, c)                  # every block's (shift, scale, gate) from ONE product over the stacked adaLN weights
+        kw = (lambda i: {"mod": mods[i]}) if mods is not None else (lambda i: {})
         outs = []
         for i, blk in enumerate(self.blocks):          # U-ViT style long skips (reference model.py:286-295)
             if i == 0:
-                x = blk(x, c, w)
+                x = blk(x, c, w, **kw(i))
             elif i > self.depth / 2:
-                x = blk(outs[-1] + outs[self.depth - i - 1], c, w)
+                x = blk(outs[-1] + outs[self.depth - i - 1], c, w, **kw(i))
             else:
-                x = blk(outs[-1], c, w)
+                x = blk(outs[-1], c, w, **kw(i))
             outs.append(x)
         return self.unpatchify(self.final_layer(x, c))
 

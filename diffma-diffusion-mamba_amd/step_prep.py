@@ -133,7 +133,18 @@ def prepare(model, dtype=None):
                 wa, wb = getattr(a, n).weight, getattr(b, n).weight
                 if wa.shape == wb.shape and wa.dtype == wb.dtype:
                     partner[id(wa)] = wb
-        plan = _PLANS[model] = dict(mixers=mixers, masters=masters, shadows={}, partner=partner)
+        # the blocks' adaLN Linear layers all read the same SiLU(c): their 16-bit copies are the rows of ONE [nblocks, 3 D, 2 D] buffer
+        # (and one [nblocks, 3 D] buffer for the biases), which `adaln_all` multiplies in one product instead of one per block
+        ada_w, ada_b = [], []
+        for m in getattr(model, "blocks", []):
+            ada = getattr(m, "adaLN_modulation", None)
+            if getattr(m, "attention_network", None) is not None and isinstance(ada, torch.nn.Sequential) and isinstance(ada[1], torch.nn.Linear) \
+                    and ada[1].bias is not None:
+                ada_w.append(ada[1].weight)
+                ada_b.append(ada[1].bias)
+        if len(ada_w) < 2 or any(w.shape != ada_w[0].shape or w.dtype != ada_w[0].dtype for w in ada_w):
+            ada_w, ada_b = [], []
+        plan = _PLANS[model] = dict(mixers=mixers, masters=masters, shadows={}, partner=partner, ada_w=ada_w, ada_b=ada_b, ada_stack={})
     mixers = plan["mixers"]
     if mixers:
         As = _NegExpAll.apply(*[m.A_log for m in mixers])
@@ -156,6 +167,14 @@ def prepare(model, dtype=None):
             fresh = any(s._use_count() > 1 for s in sh) or any(b._use_count() > n for b, n in plan.get("bases", {}).get(dt, ()))
         if fresh:
             sh, made, bases = [], {}, []
+            if plan["ada_w"]:                                      # rows of one buffer each, in block order
+                nb = len(plan["ada_w"])
+                wbase = torch.empty((nb,) + tuple(plan["ada_w"][0].shape), dtype=dt, device=masters[0].device)
+                bbase = torch.empty((nb,) + tuple(plan["ada_b"][0].shape), dtype=dt, device=masters[0].device)
+                for i, (w, b) in enumerate(zip(plan["ada_w"], plan["ada_b"])):
+                    made[id(w)], made[id(b)] = wbase[i], bbase[i]
+                plan["ada_stack"][dt] = (wbase, bbase)
+                bases += [wbase, bbase]                            # what adaln_all's autograd node saves: part of the live-graph check below
             for w in masters:
                 if id(w) in made:
                     sh.append(made.pop(id(w)))
@@ -176,3 +195,25 @@ def prepare(model, dtype=None):
             torch._foreach_copy_(sh, [w.detach() for w in masters])
         for w, s in zip(masters, sh):
             _register(w, s)
+
+
+def adaln_stack(model, dtype):
+    """([nblocks, 3 D, 2 D] weight, [nblocks, 3 D] bias) in `dtype`: the blocks' adaLN Linear layers as ONE operand, valid when every
+    row is the current shadow of its master (prepare() ran this step and nothing was written since); None otherwise."""
+    plan = _PLANS.get(model)
+    if plan is None or not plan.get("ada_w"):
+        return None
+    st = plan["ada_stack"].get(dtype)
+    if st is None:
+        return None
+    wbase, bbase = st
+    for i, (w, b) in enumerate(zip(plan["ada_w"], plan["ada_b"])):
+        sw, sb = shadow_of(w, dtype), shadow_of(b, dtype)
+        if sw is None or sb is None or sw.data_ptr() != wbase[i].data_ptr() or sb.data_ptr() != bbase[i].data_ptr():
+            return None
+    return wbase, bbase                                        # the BASES ([nblocks, 3 D, 2 D], [nblocks, 3 D]): an autograd node must save these objects
+
+
+def adaln_params(model):
+    plan = _PLANS.get(model)
+    return (plan["ada_w"], plan["ada_b"]) if plan is not None and plan.get("ada_w") else None

@@ -1352,3 +1352,55 @@ def test_route_a_model_equals_native_model(gpu, dtype):
     assert grads_a.keys() == grads_b.keys()
     bad = {k: rel_l2(grads_a[k], grads_b[k]) for k in grads_b if float(grads_b[k].norm()) > 0 and not rel_l2(grads_a[k], grads_b[k]) <= tol_g}
     assert not bad, bad
+
+
+def test_adaln_of_all_blocks_in_one_product_equals_per_block(gpu, monkeypatch):
+    """mamba_block.adaln_all: the 16-bit adaLN weights of all blocks are the rows of one buffer (step_prep) and every block's
+    (shift, scale, gate) comes from ONE product (reference: each block applies adaLN_modulation to the same c, block/mamba_block.py:
+    82-85, 101) -- same loss and the same gradient for every parameter (incl. each block's adaLN weight / bias, handed back as row
+    views of one product) as the per-block products, in the bf16 autocast step; a second step after an optimizer update still agrees
+    (the stacked copies are refreshed by prepare())."""
+    import copy
+
+    from diffma_amd import mamba_block
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa
+
+    torch.manual_seed(31)
+    net0 = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=64, depth=4, d_state=16)
+    _rerandomize(net0, 32)
+    B, L = 3, 16
+    g = torch.Generator().manual_seed(33)
+    x, y, y2 = torch.randn(B, 4, 8, 8, generator=g).to(gpu), torch.randn(B, 64, generator=g).to(gpu), torch.randn(B, L, 64, generator=g).to(gpu)
+    w = torch.sigmoid(torch.randn(B, L, 1, generator=g)).to(gpu)
+    t = torch.randint(0, 1000, (B,), generator=g).to(gpu)
+    nz = torch.randn(B, 4, 8, 8, generator=g).to(gpu)
+    d = create_diffusion("")
+    used = []
+    real = mamba_block._AdaLNAllFn.apply
+    monkeypatch.setattr(mamba_block._AdaLNAllFn, "apply", staticmethod(lambda *a: (used.append(1), real(*a))[1]))
+
+    def run(flag):
+        monkeypatch.setattr(mamba_block, "ADALN_ALL", flag)
+        net = copy.deepcopy(net0).to(gpu).train()
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0)
+        out = []
+        for _ in range(2):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = d.training_losses(net, x, t, dict(y=y, y2=y2, w=w), noise=nz)["loss"].mean()
+            loss.backward()
+            out.append((float(loss.detach()), {k: p.grad.detach().double().cpu() for k, p in net.named_parameters() if p.grad is not None}))
+            opt.step()
+        return out
+
+    ref = run(False)
+    assert not used
+    got = run(True)
+    assert len(used) == 2
+    for (la, ga), (lb, gb) in zip(got, ref):
+        assert abs(la - lb) <= 5e-3 * abs(lb), (la, lb)
+        assert ga.keys() == gb.keys()
+        bad = {k: rel_l2(ga[k], gb[k]) for k in gb if float(gb[k].norm()) > 0 and not rel_l2(ga[k], gb[k]) <= 3e-2}
+        assert not bad, bad
+        assert all(k in ga for k in gb if "adaLN_modulation" in k)
