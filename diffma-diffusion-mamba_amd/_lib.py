@@ -104,6 +104,7 @@ dm_gemm_args = _make_struct("dm_gemm_args")
 dm_repack_args = _make_struct("dm_repack_args")
 dm_adamw_tensor = _make_struct("dm_adamw_tensor")
 dm_adamw_args = _make_struct("dm_adamw_args")
+dm_training_loss_args = _make_struct("dm_training_loss_args")
 
 _lib = None
 _lock = threading.Lock()

@@ -356,11 +356,39 @@ class GaussianDiffusion:
         nll = mean_flat(nll) / math.log(2.0)
         return {"output": th.where(t == 0, nll, kl), "pred_xstart": out["pred_xstart"]}
 
+    _LOSS_ROWS = ("sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_log_variance_clipped", "log_betas",
+                  "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_mean_coef1", "posterior_mean_coef2")
+    # GPU: q_sample and everything after the denoiser call (mse, the bound's term, their gradients) as two kernels
+    # (csrc/diffusion_loss.hip); DIFFMA_FUSED_LOSS=0: the ATen chain below
+    fused_loss = os.environ.get("DIFFMA_FUSED_LOSS", "1") == "1"
+
+    def _fused_training_losses(self, model, x_start, t, model_kwargs, noise):
+        """The configuration DiffMa trains with (epsilon prediction, learned-range variance, MSE loss) on a ROCm device; None when the
+        generic path has to run."""
+        if not (self.fused_loss and x_start.is_cuda and x_start.dtype == th.float32 and noise.dtype == th.float32 and t.dtype == th.int64
+                and self.loss_type == LossType.MSE and self.model_var_type == ModelVarType.LEARNED_RANGE
+                and self.model_mean_type == ModelMeanType.EPSILON and x_start.dim() >= 3):
+            return None
+        from .. import hip_ops
+        tables = self._tables(x_start.device)
+        rows = [_TABLE_NAMES.index(n) for n in self._LOSS_ROWS]
+        with th.no_grad():
+            x_t = hip_ops.q_sample(x_start, noise, t, tables, rows)
+        out = model(x_t, t, **model_kwargs)
+        if isinstance(out, tuple) or out.shape != (x_start.shape[0], 2 * x_start.shape[1], *x_start.shape[2:]) \
+                or out.dtype not in (th.float32, th.bfloat16, th.float16):
+            raise ValueError("the denoiser must return one (B, 2C, ...) tensor with learn_sigma (reference gaussian_diffusion.py:286)")
+        mse, vb, loss = _FusedLossFn.apply(out, x_start.contiguous(), x_t, noise.contiguous(), t, tables, rows)
+        return {"mse": mse, "vb": vb, "loss": loss}
+
     def training_losses(self, model, x_start, t, model_kwargs=None, noise=None):
         """{'loss' [N], ...}: MSE on the mean prediction (+ 'vb' when the variance is learned)."""
         model_kwargs = model_kwargs or {}
         if noise is None:
             noise = th.randn_like(x_start)
+        fused = self._fused_training_losses(model, x_start, t, model_kwargs, noise)
+        if fused is not None:
+            return fused
         x_t = self.q_sample(x_start, t, noise=noise)
         terms = {}
         if self.loss_type.is_vb():
@@ -413,6 +441,32 @@ class GaussianDiffusion:
         vb, xstart_mse, mse = th.stack(vb, dim=1), th.stack(xstart_mse, dim=1), th.stack(mse, dim=1)
         prior = self._prior_bpd(x_start)
         return {"total_bpd": vb.sum(dim=1) + prior, "prior_bpd": prior, "vb": vb, "xstart_mse": xstart_mse, "mse": mse}
+
+
+class _FusedLossFn(th.autograd.Function):
+    """(mse, vb, loss) per sample from the model output; the forward launch also leaves d(term)/d(model output), the backward scales it
+    by the incoming per-sample gradients (loss = mse + vb: its gradient goes to both halves)."""
+
+    @staticmethod
+    def forward(ctx, out, x_start, x_t, noise, t, tables, rows):
+        from .. import hip_ops
+        mse, vb, loss, grad = hip_ops.training_loss_fwd(out.contiguous(), x_start, x_t, noise, t, tables, rows)
+        ctx.save_for_backward(grad)
+        ctx.out_dtype = out.dtype
+        return mse, vb, loss
+
+    @staticmethod
+    def backward(ctx, g_mse, g_vb, g_loss):
+        from .. import hip_ops
+        (grad,) = ctx.saved_tensors
+        zero = None
+        def total(a, b):
+            nonlocal zero
+            if a is None and b is None:
+                zero = grad.new_zeros(grad.shape[0]) if zero is None else zero
+                return zero
+            return a if b is None else b if a is None else a + b
+        return hip_ops.training_loss_bwd(grad, total(g_mse, g_loss), total(g_vb, g_loss), ctx.out_dtype), None, None, None, None, None, None
 
 
 def _extract_into_tensor(arr, timesteps, broadcast_shape):

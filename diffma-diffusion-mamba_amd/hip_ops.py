@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from ._lib import (DM_BF16, DM_F16, DM_F32, DM_FLAG_A_SHARED, DM_FLAG_DELTA_ACTIVATED, DM_FLAG_DX_MERGED, DM_FLAG_PARTIAL_COMPACT, DM_FLAG_OUT_ACCUMULATE, DM_FLAG_DELTA_SOFTPLUS, DM_FLAG_DOUT_PER_SEQ, DM_FLAG_SCAN_CHUNKED, DM_FLAG_SCAN_SEQUENTIAL, DM_FLAG_SILU, dm_blend_args, dm_gate_head_args, dm_dtproj_bwd_args, dm_conv_bwd_args, dm_rmsnorm_merge_args, dm_colsum_args, dm_sum_partials_args,
-                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args, dm_repack_args)
+                   dm_conv_fwd_args, dm_conv_xproj_bwd_args, dm_conv_xproj_fwd_args, dm_diffusion_step_args, dm_ln_mod_args, dm_ssd_bwd_args, dm_ssd_fwd_args, dm_merge_args, dm_gate_bwd_args, dm_dtproj_args, dm_scan_bwd_args, dm_scan_fwd_args, dm_gemm_args, dm_repack_args, dm_training_loss_args)
 
 _DT = {torch.float32: DM_F32, torch.bfloat16: DM_BF16, torch.float16: DM_F16}
 SCAN_CKPT_EVERY = 4          # forward checkpoint spacing = backward sub-chunk length (csrc/scan_bwd_impl.h BWD_SUB)
@@ -1126,6 +1126,60 @@ def diffusion_step(model_out, x, t, noise, tables, rows, *, ddim=False, eta=0.0,
     a.sample, a.pred_xstart = _ptr(sample), _ptr(x0)
     _launch("dm_diffusion_step", a, x, B * C * hw * (2 * model_out.element_size() + 4 * 4))
     return sample, x0
+
+
+def _loss_args(x, t, tables, rows, out_dtype_code):
+    B, C = x.shape[:2]
+    a = dm_training_loss_args()
+    a.batch, a.channels, a.hw, a.T = B, C, x[0, 0].numel(), tables.shape[1]
+    a.out_dtype = out_dtype_code
+    (a.row_sqrt_ac, a.row_sqrt_1mac, a.row_post_logvar, a.row_log_betas, a.row_sqrt_recip_ac, a.row_sqrt_recipm1_ac, a.row_coef1,
+     a.row_coef2) = rows
+    a.t, a.tables = _ptr(t), _ptr(tables)
+    return a
+
+
+def q_sample(x_start, noise, t, tables, rows):
+    """x_t = sqrt(abar_t) x_start + sqrt(1 - abar_t) noise in one launch (csrc/diffusion_loss.hip); fp32 (B, C, ...), t int64 [B]."""
+    _require_gpu(x_start, noise, t, tables)
+    assert x_start.dtype == torch.float32 and noise.dtype == torch.float32 and t.dtype == torch.int64 and tables.dtype == torch.float32
+    x_start, noise = x_start.contiguous(), noise.contiguous()
+    out = torch.empty_like(x_start)
+    a = _loss_args(x_start, t, tables, rows, DM_F32)
+    a.x_start, a.noise, a.x_t_out = _ptr(x_start), _ptr(noise), _ptr(out)
+    _launch("dm_q_sample", a, x_start, 3 * x_start.numel() * 4)
+    return out
+
+
+def training_loss_fwd(model_out, x_start, x_t, noise, t, tables, rows):
+    """(mse [B], vb [B], loss [B], grad fp32 [B, 2C, ...]): the per-sample terms of GaussianDiffusion.training_losses and their gradient
+    with respect to the model output, one launch (workgroup = sample)."""
+    _require_gpu(model_out, x_start, x_t, noise, t, tables)
+    B, C = x_start.shape[:2]
+    assert model_out.shape[0] == B and model_out.shape[1] == 2 * C and model_out.is_contiguous()
+    assert all(v.dtype == torch.float32 and v.is_contiguous() for v in (x_start, x_t, noise)) and t.dtype == torch.int64
+    dev = x_start.device
+    terms = torch.empty((3, B), dtype=torch.float32, device=dev)
+    grad = torch.empty(model_out.shape, dtype=torch.float32, device=dev)
+    a = _loss_args(x_start, t, tables, rows, dtype_code(model_out))
+    a.model_out, a.x_start, a.x_t, a.noise = _ptr(model_out), _ptr(x_start), _ptr(x_t), _ptr(noise)
+    a.mse, a.vb, a.loss, a.grad = _ptr(terms[0]), _ptr(terms[1]), _ptr(terms[2]), _ptr(grad)
+    _launch("dm_training_loss", a, x_start, model_out.numel() * (model_out.element_size() + 4) + 3 * x_start.numel() * 4)
+    return terms[0], terms[1], terms[2], grad
+
+
+def training_loss_bwd(grad, g_eps, g_v, out_dtype):
+    """grad_out (dtype of the model output) = per-sample scalars times the stored gradient: (g_eps[b] * grad[b, :C] | g_v[b] * grad[b, C:])."""
+    _require_gpu(grad, g_eps, g_v)
+    B, C2 = grad.shape[:2]
+    out = torch.empty(grad.shape, dtype=out_dtype, device=grad.device)
+    a = dm_training_loss_args()
+    a.batch, a.channels, a.hw, a.T = B, C2 // 2, grad[0, 0].numel(), 1
+    a.out_dtype = _DT[out_dtype]
+    g_eps, g_v = g_eps.float().contiguous(), g_v.float().contiguous()
+    a.grad, a.g_eps, a.g_v, a.grad_out = _ptr(grad), _ptr(g_eps), _ptr(g_v), _ptr(out)
+    _launch("dm_training_loss_bwd", a, grad, grad.numel() * (4 + out.element_size()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

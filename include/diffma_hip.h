@@ -80,6 +80,36 @@ enum {
 };
 
 /* ------------------------------------------------------------------------------------------------
+ * The diffusion wrapper around the denoiser call of a training step (ABI 29): GaussianDiffusion.training_losses (reference
+ * diffusion/gaussian_diffusion.py:715-789) for epsilon prediction + learned-range variance + MSE loss (create_diffusion("")).
+ *   dm_q_sample         x_t_out = sqrt(abar_t) x_start + sqrt(1 - abar_t) noise                                  (:215-230)
+ *   dm_training_loss    per sample: mse = mean (noise - eps)^2, vb = the variational-bound term in bits/dim (KL for t > 0, discretised
+ *                       decoder NLL at t = 0; the mean prediction detached, :682-713, :752-766; diffusion_utils.py:10-88), loss = mse + vb,
+ *                       and grad[b] = (d mse_b / d eps | d vb_b / d v), fp32 [batch][2 channels][hw]
+ *   dm_training_loss_bwd  grad_out (model output dtype) = (g_eps[b] * grad[b, :C] | g_v[b] * grad[b, C:])
+ * model_out: [batch][2 channels][hw] contiguous (eps | variance logits), dtype out_dtype; x_start, x_t, noise fp32 [batch][channels][hw];
+ * t int64 [batch]; tables fp32 [nrows][T] with the row numbers of sqrt(abar), sqrt(1 - abar), log(posterior variance, clipped),
+ * log(beta), sqrt(1 / abar), sqrt(1 / abar - 1), posterior mean coefficients 1 and 2.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t batch, channels, hw, T;
+    int32_t out_dtype, _pad;
+    int32_t row_sqrt_ac, row_sqrt_1mac, row_post_logvar, row_log_betas, row_sqrt_recip_ac, row_sqrt_recipm1_ac, row_coef1, row_coef2;
+    const void *model_out;
+    const float *x_start, *x_t, *noise;
+    const int64_t *t;
+    const float *tables;
+    float *x_t_out;
+    float *mse, *vb, *loss, *grad;
+    const float *g_eps, *g_v;
+    void *grad_out;
+} dm_training_loss_args;
+
+int dm_q_sample(const dm_training_loss_args *args, void *stream);
+int dm_training_loss(const dm_training_loss_args *args, void *stream);
+int dm_training_loss_bwd(const dm_training_loss_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
  * The optimiser step of the training loop (ABI 29): AdamW + the EMA of the weights in ONE pass over the parameters.
  * Reference: train.py:153-166 (`torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0)`), train.py:259-264 (`opt.step()`,
  * `update_ema(ema, model.module)`), train.py:36-47 (ema = decay * ema + (1 - decay) * param).  Arithmetic of torch's fused AdamW
