@@ -234,12 +234,13 @@ __global__ __launch_bounds__(64 * CONV_BWD_WAVES) void conv_bwd_kernel(const mix
 #pragma unroll
             for (int wv = 0; wv < CONV_BWD_WAVES; ++wv) acc[i] += part_lds[wv][i][lane];
         }
-        float* dwp = p.dw_partial + (((int64_t)s * p.nchunk + blockIdx.y) * p.dim + d) * W;
+        const int64_t prow = (int64_t)s * p.nchunk + blockIdx.y;
+        float* dwp = p.part_ss ? p.dw_partial + prow * p.part_ss + (int64_t)d * W : p.dw_partial + (prow * p.dim + d) * W;
 #pragma unroll
         for (int i = 0; i < W * VEC; ++i) dwp[i] = acc[i];
         if (p.db_partial) {
 #pragma unroll
-            for (int v = 0; v < VEC; ++v) p.db_partial[((int64_t)s * p.nchunk + blockIdx.y) * p.dim + d + v] = acc[W * VEC + v];
+            for (int v = 0; v < VEC; ++v) p.db_partial[(p.part_ss ? prow * p.part_ss : prow * p.dim) + d + v] = acc[W * VEC + v];
         }
     }
 }

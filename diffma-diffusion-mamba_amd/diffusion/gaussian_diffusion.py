@@ -369,6 +369,8 @@ class GaussianDiffusion:
                 and self.loss_type == LossType.MSE and self.model_var_type == ModelVarType.LEARNED_RANGE
                 and self.model_mean_type == ModelMeanType.EPSILON and x_start.dim() >= 3):
             return None
+        if th.is_grad_enabled() and (x_start.requires_grad or noise.requires_grad):
+            return None                         # the kernels give the gradient with respect to the MODEL OUTPUT only (what training needs)
         from .. import hip_ops
         tables = self._tables(x_start.device)
         rows = [_TABLE_NAMES.index(n) for n in self._LOSS_ROWS]

@@ -636,8 +636,10 @@ def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=Tru
     nchunk = lib.dm_conv_nchunk(L)
     dev = x.device
     dx = torch.empty((ndir * Bsz, L, Dm), dtype=x.dtype, device=dev)
-    dw = torch.empty((ndir * Bsz, nchunk, Dm, W), dtype=torch.float32, device=dev)
-    db = torch.empty((ndir * Bsz, nchunk, Dm), dtype=torch.float32, device=dev)
+    # dw | db partial rows in ONE buffer (part_ss): one column sum instead of two
+    rows = ndir * Bsz * nchunk
+    part = torch.empty((rows, Dm * (W + 1)), dtype=torch.float32, device=dev)
+    dw, db = part[:, :Dm * W], part[:, Dm * W:]
     a = dm_conv_bwd_args()
     a.batch, a.dim, a.seqlen, a.width, a.ndir = Bsz, Dm, L, W, ndir
     a.io_dtype, a.w_dtype = dtype_code(x), dtype_code(weight)
@@ -649,9 +651,11 @@ def gather_conv1d_bwd(x, weight, bias, dout, *, row_index=None, ndir=1, silu=Tru
     a.x_sb, a.x_sl, a.x_sd = x.stride()
     a.do_ss, a.do_sl, a.do_sd = dout.stride()
     a.dx_ss, a.dx_sl, a.dx_sd = dx.stride()
+    a.part_ss = Dm * (W + 1)
     _launch("dm_gather_conv1d_bwd", a, x, 3 * ndir * Bsz * L * Dm * x.element_size())
-    # partial rows -> one column sum each (ATen's reduction of these shapes takes ~21 us per call, dm_colsum_f32 ~5)
-    return dx, colsum(dw.view(ndir * Bsz * nchunk, Dm * W), True).view(Dm, W), colsum(db.view(ndir * Bsz * nchunk, Dm), True)
+    # partial rows -> ONE column sum (ATen's reduction of these shapes takes ~21 us per call, dm_colsum_f32 ~5)
+    psum = colsum(part, True)
+    return dx, psum[:Dm * W].view(Dm, W), psum[Dm * W:]
 
 
 def token_merge(slabs, *, row_index=None, out=None, out_dtype=None, gate=None, pre_out=None):

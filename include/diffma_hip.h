@@ -296,6 +296,9 @@ typedef struct {
     int64_t x_sb, x_sl, x_sd;
     int64_t do_ss, do_sl, do_sd;
     int64_t dx_ss, dx_sl, dx_sd;
+    int64_t part_ss;          /* ABI 29: element stride between partial rows of dw_partial AND db_partial; 0 = dense (dim * width / dim).
+                                 With part_ss = dim * (width + 1) and db_partial = dw_partial + dim * width the two live in ONE
+                                 [rows][dim * (width + 1)] buffer that one dm_colsum_f32 reduces. */
 } dm_conv_bwd_args;
 
 int dm_gather_conv1d_bwd(const dm_conv_bwd_args *args, void *stream);
