@@ -85,6 +85,22 @@ class SyntheticLatents:
             yield z, y, y2, w
 
 
+GRAPH_AUTO_MAX_BATCH = 32      # `graph_train: auto`: per-GPU batches up to this are replayed from a hipGraph
+
+
+def graph_train_decision(setting, device_type, accumulation_steps, local_batch, fp16):
+    """graph_train = true / false / "auto".  The reference's own configuration (config/brain.yaml: global batch 8 on 8 GPUs) runs ONE
+    sample per GPU, where an eager step is bound by the host's launch rate (~50 ms) and the replayed step takes 6.5 ms: "auto" turns the
+    graphed step on for per-GPU batches up to GRAPH_AUTO_MAX_BATCH when nothing rules it out (a ROCm device, no gradient accumulation,
+    not fp16 -- the GradScaler's skip decision is a host branch); "true" insists (and train() raises for fp16)."""
+    if isinstance(setting, str):
+        v = setting.strip().lower()
+        if v == "auto":
+            return device_type == "cuda" and accumulation_steps == 1 and not fp16 and local_batch <= GRAPH_AUTO_MAX_BATCH
+        setting = v in ("1", "true", "yes", "on")
+    return bool(setting) and device_type == "cuda" and accumulation_steps == 1
+
+
 def build_ct_encoder(args, latent, device):
     """The frozen CT_Encoder of train.py:158-169 when its checkpoint is there (or `synthetic_ct_encoder: true` asks for a
     randomly initialised one); None otherwise."""
@@ -164,7 +180,8 @@ def main(args):
     model = model.to(device)
     # graph_train: replay the whole optimisation step from a hipGraph (pays off below ~100 samples per GPU,
     # where the eager step is bound by the host's launch rate -- e.g. the reference's own global_batch_size of 8)
-    use_graph = bool(args.get("graph_train", False)) and device.type == "cuda" and int(args.accumulation_steps) == 1
+    use_graph = graph_train_decision(args.get("graph_train", False), device.type, int(args.accumulation_steps), args.global_batch_size // world,
+                                     bool(args.autocast) and args.get("amp_dtype", "bf16") == "fp16")
     if use_graph:
         ddp = model                                  # no reducer hooks inside the captured backward: with several ranks the graphed
         if world > 1:                                # step all-reduces the flattened gradients itself (graphed.GraphedTrainStep)
@@ -296,7 +313,9 @@ def cli(argv=None):
     p.add_argument("--max-steps", type=int, default=None)
     p.add_argument("--grad-compression", default=None, choices=["none", "bf16", "fp16"],
                    help="all-reduce 16-bit copies of the DDP gradient buckets (opt-in; default none = fp32 like the reference)")
-    p.add_argument("--graph-train", action="store_true", help="replay the whole optimisation step from a hipGraph (for small batches; with several ranks: two graphs around one gradient all-reduce)")
+    p.add_argument("--graph-train", nargs="?", const="true", default=None, choices=["true", "false", "auto"],
+                   help="replay the whole optimisation step from a hipGraph (for small batches; with several ranks: two graphs around one "
+                        "gradient all-reduce); `auto`: on for per-GPU batches up to 32.  Also the YAML key graph_train")
     p.add_argument("--config", type=str, required=True)
     a = p.parse_args(argv)
     over = {k: v for k, v in vars(a).items() if v is not None and k != "config"}

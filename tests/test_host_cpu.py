@@ -507,3 +507,20 @@ def test_fused_optimizer_predicate_and_state_layout():
         assert fields[k] is ctypes.c_double, k
     assert [f for f, _ in _lib.STRUCT_FIELDS["dm_adamw_tensor"]] == ["p", "m", "v", "g", "ema", "step", "n"]
     assert ctypes.sizeof(_lib.dm_adamw_tensor) == 56                                   # 7 x 8 bytes: the rows FusedAdamWEMA writes as int64
+
+
+def test_graph_train_setting_true_false_auto():
+    """train.graph_train_decision: `graph_train: auto` replays the step from a hipGraph exactly where the reference's own configuration
+    sits (config/brain.yaml: one sample per GPU) and leaves large batches, gradient accumulation, fp16 and the CPU alone; booleans and
+    the CLI's strings keep their meaning."""
+    from diffma_amd.train import GRAPH_AUTO_MAX_BATCH, cli, graph_train_decision as dec
+
+    assert dec("auto", "cuda", 1, 1, False) and dec("auto", "cuda", 1, GRAPH_AUTO_MAX_BATCH, False)
+    assert not dec("auto", "cuda", 1, GRAPH_AUTO_MAX_BATCH + 1, False)
+    assert not dec("auto", "cuda", 2, 1, False) and not dec("auto", "cuda", 1, 1, True) and not dec("auto", "cpu", 1, 1, False)
+    assert dec(True, "cuda", 1, 512, False) and dec("true", "cuda", 1, 512, True) and not dec(True, "cpu", 1, 1, False)
+    assert not dec(False, "cuda", 1, 1, False) and not dec("false", "cuda", 1, 1, False) and not dec(True, "cuda", 4, 1, False)
+    cfg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "diffma_l2_synthetic.yaml")
+    assert cli(["--config", cfg]).get("graph_train", False) in (False, None)          # absent on the command line: the YAML decides
+    assert cli(["--config", cfg, "--graph-train"]).graph_train == "true"
+    assert cli(["--config", cfg, "--graph-train", "auto"]).graph_train == "auto"
