@@ -524,3 +524,57 @@ def test_graph_train_setting_true_false_auto():
     assert cli(["--config", cfg]).get("graph_train", False) in (False, None)          # absent on the command line: the YAML decides
     assert cli(["--config", cfg, "--graph-train"]).graph_train == "true"
     assert cli(["--config", cfg, "--graph-train", "auto"]).graph_train == "auto"
+
+
+def test_adaln_stack_is_the_blocks_shadows_and_one_product_equals_sixteen():
+    """step_prep keeps the blocks' 16-bit adaLN weights / biases as the rows of ONE buffer (adaln_stack) and mamba_block._AdaLNAllFn
+    multiplies that buffer once (reference: every block applies its adaLN_modulation to the same c, block/mamba_block.py:82-85, 101).
+    On the CPU: the stack's rows ARE the per-weight shadows, the stack-wide product equals the per-block Linear layers (outputs and the
+    gradients of SiLU(c), every weight and every bias), a weight update is picked up by the next prepare(), a live autograd graph keeps
+    the buffer it saved, and a stale row makes adaln_stack return None."""
+    import torch.nn.functional as F
+
+    from diffma_amd import mamba_block, step_prep
+    from diffma_amd.model import DiffMa
+
+    torch.manual_seed(2)
+    net = DiffMa(input_size=8, patch_size=2, strip_size=2, hidden_size=32, depth=4, d_state=16)
+    with torch.no_grad():
+        for b in net.blocks:
+            b.adaLN_modulation[1].weight.normal_(0, 0.05)
+            b.adaLN_modulation[1].bias.normal_(0, 0.05)
+    dt = torch.bfloat16
+    step_prep.prepare(net, dtype=dt)
+    st = step_prep.adaln_stack(net, dt)
+    ws, bs = step_prep.adaln_params(net)
+    assert st is not None and len(ws) == 4 and st[0].shape == (4,) + tuple(ws[0].shape) and st[1].shape == (4,) + tuple(bs[0].shape)
+    for i, (w, b) in enumerate(zip(ws, bs)):
+        assert step_prep.shadow_of(w, dt).data_ptr() == st[0][i].data_ptr() and step_prep.shadow_of(b, dt).data_ptr() == st[1][i].data_ptr()
+        torch.testing.assert_close(st[0][i].float(), w.detach().to(dt).float())
+    sc = torch.randn(3, 64).to(dt).requires_grad_(True)
+    outs = mamba_block._AdaLNAllFn.apply(sc, st[0], st[1], *ws, *bs)
+    gos = [torch.randn(3, ws[0].shape[0]).to(dt) for _ in range(4)]
+    torch.autograd.backward(outs, gos)
+    g_sc, g_w, g_b = sc.grad.clone(), [w.grad.clone() for w in ws], [b.grad.clone() for b in bs]
+    sc.grad = None
+    for p in ws + bs:
+        p.grad = None
+    ref = [F.linear(sc, w.to(dt), b.to(dt)) for w, b in zip(ws, bs)]
+    torch.autograd.backward(ref, gos)
+    for a, r in zip(outs, ref):
+        torch.testing.assert_close(a.float(), r.float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(g_sc.float(), sc.grad.float(), rtol=3e-2, atol=3e-2)
+    for i in range(4):
+        torch.testing.assert_close(g_w[i], ws[i].grad, rtol=2e-2, atol=2e-2)
+        torch.testing.assert_close(g_b[i], bs[i].grad, rtol=2e-2, atol=2e-2)
+    # a live graph keeps the buffer it saved; the update lands in a new one
+    held = mamba_block._AdaLNAllFn.apply(sc, st[0], st[1], *ws, *bs)
+    with torch.no_grad():
+        ws[1].add_(1.0)
+    assert step_prep.adaln_stack(net, dt) is None                       # row 1 is stale until the next prepare()
+    step_prep.prepare(net, dtype=dt)
+    st2 = step_prep.adaln_stack(net, dt)
+    assert st2 is not None and st2[0].data_ptr() != st[0].data_ptr()
+    torch.testing.assert_close(st2[0][1].float(), ws[1].detach().to(dt).float())
+    torch.testing.assert_close(st[0][1].float(), (ws[1].detach() - 1.0).to(dt).float(), rtol=1e-2, atol=1e-2)     # what `held` saw
+    del held
