@@ -34,7 +34,7 @@ HBM_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md: measured float4 copy ceiling
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -55,7 +55,12 @@ def parse():
     ap.add_argument("--sampler", default="ddpm250", choices=["ddpm250", "ddim50"], help="sample mode: 250-step respaced DDPM (p_sample) or 50-step DDIM")
     ap.add_argument("--route-a", action="store_true", help="the mixers call mamba_inner_fn three times per mixer exactly as the reference's Mamba.forward does (INTEGRATION.md route A) instead of the fused 3-direction operator: what the plain import swap delivers")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (sample mode: the denoiser call; train mode: the whole optimisation step, with several ranks as two graphs around one gradient all-reduce -- for small batches where the eager step is host-bound)")
-    return ap.parse_args()
+    ap.add_argument("--no-config-legs", action="store_true",
+                    help="skip the short legs after the headline region (BASELINE configs 2 / 4 / 5 and the one-sample-per-GPU graphed step)")
+    ap.add_argument("--legs", default="", help="comma list of the legs to run after the headline region (c2,c4,c5,c3_one_sample_graph); "
+                                               "default: all four on one GPU, c3_one_sample_graph only on several")
+    ap.add_argument("--leg-steps", type=int, default=10, help="timed steps of each leg")
+    return ap.parse_args(argv)
 
 
 _T0 = time.perf_counter()
@@ -450,14 +455,48 @@ def _merge(intervals):
     return out
 
 
+def launch_plan(gpus, environ, visible_gpus, argv):
+    """What `python bench.py --gpus N ...` does when it is NOT already a rank of a torch.distributed.run job (reference
+    train.py:153,190 is started by torchrun; load_data.py:86 shards by rank).  Pure function (CPU-tested):
+      ("run", None)       : N == 1, or the process already is a rank (WORLD_SIZE set): run in this process;
+      ("error", message)  : more GPUs requested than visible, or WORLD_SIZE disagrees with --gpus;
+      ("relaunch", cmd)   : re-execute under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on 127.0.0.1."""
+    ws = environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            return "error", f"bench.py: --gpus {gpus} but WORLD_SIZE={ws}: the launcher's --nproc-per-node and --gpus must agree"
+        return "run", None
+    if gpus <= 1:
+        return "run", None
+    if visible_gpus < gpus:
+        return "error", f"bench.py: {gpus} GPUs requested, {visible_gpus} visible: run on a node with >= {gpus} MI355X (or lower --gpus)"
+    import socket
+    with socket.socket() as so:                       # a free port for the rendezvous
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return "relaunch", [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    action, what = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), sys.argv[1:])
+    if action == "error":
+        print(what, file=sys.stderr, flush=True)
+        sys.exit(2)
+    if action == "relaunch":
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")      # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+        _log("not under torch.distributed.run: re-executing as " + " ".join(what))
+        sys.exit(subprocess.run(what, env=env).returncode)           # rank 0 of the children prints the ONE JSON line on the shared stdout
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     import torch.distributed as dist
 
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs cuda:{local}, {torch.cuda.device_count()} GPUs visible", file=sys.stderr, flush=True)
+        sys.exit(2)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     force_ddp = os.environ.get("BENCH_FORCE_DDP") == "1"          # exercise the DDP/RCCL path on a single GPU (testing only)
@@ -466,9 +505,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)          # RCCL over xGMI
 
-    from diffma_amd import _lib, hip_ops
-    from diffma_amd.diffusion import create_diffusion
-    from diffma_amd.model import DiffMa_models
+    from diffma_amd import _lib
 
     _lib.load()                                                  # fail loudly if the HIP library is missing
     if args.gemm_tuning != "off":
@@ -480,6 +517,80 @@ def main():
         gemm_tuning.enable_tuned_gemms(tune_missing=args.gemm_tuning != "frozen", write_file=wf)
     if args.route_a:
         install_route_a()
+    res = run_workload(args, dev, rank, world, force_ddp, headline=True)
+    legs = config_legs(args, dev, rank, world, force_ddp)
+    if rank == 0 and legs:
+        res["configs"] = legs
+        res["roofline"]["configs"] = legs       # the driver's record keeps `roofline` whole and only the NAMES of other extra keys
+    finish(res, rank, world, force_ddp)
+
+
+LEG_SPECS = {
+    # BASELINE.json configs[1], [3], [4] and the regime the reference's own brain.yaml runs config [2] in (global batch 8 on 8 GPUs)
+    "c2": dict(model="DiffMa-B/4", mode="sample", sampler="ddpm250", batch_per_gpu=64, graph=True, use_mamba2=False,
+               what="BASELINE config 2: DiffMa-B/4 250-step respaced DDPM p_sample step (reference sample.py:29-115)"),
+    "c4": dict(model="DiffMa-XL/2", mode="train", sampler="ddpm250", batch_per_gpu=256, graph=False, use_mamba2=True,
+               what="BASELINE config 4: DiffMa-XL/2 --use-mamba2 training step, bf16 autocast"),
+    "c5": dict(model="DiffMa-XXL/2", mode="sample", sampler="ddim50", batch_per_gpu=64, graph=True, use_mamba2=False,
+               what="BASELINE config 5: DiffMa-XXL/2 50-step DDIM ddim_sample step"),
+    "c3_one_sample_graph": dict(model="DiffMa-L/2", mode="train", sampler="ddpm250", batch_per_gpu=1, graph=True, use_mamba2=False,
+                                what="BASELINE config 3 at the reference's own batch (brain.yaml: global batch 8 on 8 GPUs = one sample per GPU): "
+                                     "the step replayed from hipGraphs (one graph on one GPU, two around ONE gradient all-reduce on several)"),
+}
+
+
+def config_legs(args, dev, rank, world, force_ddp):
+    """Short legs AFTER the headline timed region, so that every BASELINE configuration has a driver-timed number: same timing
+    rule as the headline (barrier + synchronize on both sides, max over ranks), `--leg-steps` steps each.  Sampling configs are
+    replicas (no collective): one GPU only.  Returns {name: summary} on rank 0, None elsewhere."""
+    import gc
+    default_run = (args.model == "DiffMa-L/2" and args.mode == "train" and not args.use_mamba2 and not args.route_a and not args.graph
+                   and args.dtype == "bf16")
+    if args.no_config_legs or not default_run:
+        return None
+    names = [n for n in args.legs.split(",") if n] or (list(LEG_SPECS) if world == 1 and not force_ddp else ["c3_one_sample_graph"])
+    out = {}
+    for name in names:
+        spec = dict(LEG_SPECS[name])
+        what = spec.pop("what")
+        la = copy.copy(args)
+        for k, v in spec.items():
+            setattr(la, k, v)
+        la.steps, la.warmup, la.cpu_steps, la.no_extras, la.torch_profile = args.leg_steps, 3, 0, True, ""
+        gc.collect()
+        torch.cuda.empty_cache()
+        t0 = time.perf_counter()
+        try:
+            r = run_workload(la, dev, rank, world, force_ddp, headline=False)
+        except Exception as e:                       # a leg must never take the headline line down with it
+            if world > 1:
+                raise                                # ... but with peers in a collective there is no safe way on
+            _log(f"leg {name} FAILED: {type(e).__name__}: {e}")
+            out[name] = {"what": what, "error": f"{type(e).__name__}: {str(e)[:300]}"}
+            continue
+        if rank == 0:
+            rf = r["roofline"]
+            out[name] = {"what": what, "workload": r["config"]["workload"], "ms_per_step": r["ms_per_step"], "samples_steps_per_s": r["value"],
+                         "steps": r["steps"], "warmup": r["warmup"], "n_gpus": world, "global_batch": r["config"]["global_batch"],
+                         "dominant_kernel": rf["kernel"], "bound": rf["bound"], "frac": rf["frac"], "achieved": rf["achieved"], "unit": rf["unit"],
+                         "avg_us": rf["avg_us"], "leg_wall_s": round(time.perf_counter() - t0, 1)}
+            if r.get("comm"):
+                out[name]["comm"] = r["comm"]
+            _log(f"leg {name}: {r['ms_per_step']:.2f} ms/step ({time.perf_counter() - t0:.0f} s)")
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
+
+
+def run_workload(args, dev, rank, world, force_ddp, headline):
+    """One workload: build the model, warm up, time `args.steps` steps (barrier + synchronize on both sides, max over ranks) and,
+    on rank 0, return the JSON record (None on the other ranks)."""
+    import torch.distributed as dist
+
+    from diffma_amd import hip_ops
+    from diffma_amd.diffusion import create_diffusion
+    from diffma_amd.model import DiffMa_models
+
     torch.manual_seed(args.global_seed * world + rank)           # reference seed rule (train.py:99)
     model = DiffMa_models[args.model](input_size=28, dt_rank=16, d_state=16, use_mamba2=args.use_mamba2)
     rerandomize_zero_init(model, 1)
@@ -709,6 +820,12 @@ def main():
                 res["roofline"]["gemm_own_kernels_ms_per_step"] = res["gemm"]["own_kernels"]["ms_per_step"]
         if world == 1 and args.cpu_steps > 0 and args.mode == "train":
             res["cpu_baseline"] = cpu_baseline(args, tokens)
+    return res if rank == 0 else None
+
+
+def finish(res, rank, world, force_ddp):
+    import torch.distributed as dist
+
     # RCCL writes its banner / warnings through C stdio (block-buffered on a pipe, NCCL_DEBUG=VERSION is set on the GPU boxes):
     # every rank flushes that before the group goes away, and rank 0 prints afterwards, so that the JSON line is the LAST line
     # of the merged stdout

@@ -78,25 +78,39 @@ class _LnModFn(torch.autograd.Function):
                 dshift.to(shift.dtype) if has_mod else None, dscale.to(scale.dtype) if has_mod else None, None, None, None, None)
 
 
-_MASK_ONCE = [None]
+import threading
+
+_MASK_TLS = threading.local()          # per host thread: two threads driving forwards on two streams never share a copy
+
+
+def drop_mask_cache():
+    """Forget the cached soft-mask copy of this thread.  Called by DiffMa.forward at the end of a forward that ran inside a stream
+    capture (the copy lives in THAT graph's private pool: a later capture with the same mask object must make its own) and by
+    step_prep.invalidate() (writers that do not bump `_version`: graph replays, `.data` assignments)."""
+    _MASK_TLS.ent = None
 
 
 def _mask_once(w, B, L, dtype):
     """The soft mask as a contiguous [B, L] tensor in the modulation dtype: every block of the denoiser applies the SAME mask
     (reference block/mamba_block.py:103), so it is reshaped and cast once per mask tensor instead of once per block (a cast launch
-    per block and step at the reference's batch).  Keyed on the tensor object and its version; held weakly."""
+    per block and step at the reference's batch).  Keyed on the tensor object, its version, step_prep's generation counter and the
+    capture state; held weakly; thread-local."""
     import weakref
 
-    ent = _MASK_ONCE[0]
+    from . import step_prep
+
+    ent = getattr(_MASK_TLS, "ent", None)
     grad = w.requires_grad and torch.is_grad_enabled()
     # a copy made outside a stream capture must not be baked into a captured graph (it is freed when the next mask replaces it) and a
-    # copy made inside one lives in that graph's pool: the capture state is part of the key
+    # copy made inside one lives in that graph's pool (and is dropped when that forward ends): the capture state is part of the key
     cap = w.is_cuda and torch.cuda.is_current_stream_capturing()
-    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == dtype and ent[3].shape == (B, L) and ent[4] == cap and not grad:
+    gen = step_prep._GEN[0]
+    if ent is not None and ent[0]() is w and ent[1] == w._version and ent[2] == dtype and ent[3].shape == (B, L) and ent[4] == cap \
+            and ent[5] == gen and not grad:
         return ent[3]
     m = w.reshape(B, L).contiguous().to(dtype)
     if not grad:
-        _MASK_ONCE[0] = (weakref.ref(w), w._version, dtype, m, cap)
+        _MASK_TLS.ent = (weakref.ref(w), w._version, dtype, m, cap, gen)
     return m
 
 

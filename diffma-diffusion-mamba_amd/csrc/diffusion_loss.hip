@@ -26,7 +26,11 @@ __global__ __launch_bounds__(256) void q_sample_kernel(const dm_training_loss_ar
     const int64_t total = (int64_t)p.batch * per;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int b = (int)(e / per);
-        const float* tab = p.tables + p.t[b];
+        const int64_t tb = p.t[b];
+        // a timestep outside [0, T) (respaced / unspaced mix-up) must not read beyond the tables: the sample is POISONED with NaN so
+        // that the loss says so (the generic ATen path trips an index assert there; precondition stated in diffma_hip.h)
+        if ((uint64_t)tb >= (uint64_t)p.T) { p.x_t_out[e] = __builtin_nanf(""); continue; }
+        const float* tab = p.tables + tb;
         p.x_t_out[e] = tab[(int64_t)p.row_sqrt_ac * p.T] * p.x_start[e] + tab[(int64_t)p.row_sqrt_1mac * p.T] * p.noise[e];
     }
 }
@@ -50,6 +54,13 @@ __global__ __launch_bounds__(DL_THREADS) void training_loss_kernel(const dm_trai
     const int b = blockIdx.x;
     const int64_t per = (int64_t)p.channels * p.hw;
     const int64_t t = p.t[b];
+    if ((uint64_t)t >= (uint64_t)p.T) {                            // out-of-range timestep: NaN loss and gradient for this sample, no table read
+        const float qnan = __builtin_nanf("");
+        float* Gb = p.grad + (int64_t)b * 2 * per;
+        for (int64_t r = threadIdx.x; r < 2 * per; r += DL_THREADS) Gb[r] = qnan;
+        if (threadIdx.x == 0) { p.mse[b] = qnan; p.vb[b] = qnan; p.loss[b] = qnan; }
+        return;
+    }
     const float* tab = p.tables + t;
     const float sr = tab[(int64_t)p.row_sqrt_recip_ac * p.T], srm1 = tab[(int64_t)p.row_sqrt_recipm1_ac * p.T];
     const float minl = tab[(int64_t)p.row_post_logvar * p.T], maxl = tab[(int64_t)p.row_log_betas * p.T];

@@ -230,7 +230,6 @@ class GraphedTrainStep:
         with torch.no_grad():
             p_snap = [p.detach().clone() for p in model.parameters()]
             e_snap = [p.detach().clone() for p in self._ep]
-            o_snap = {id(v): v.detach().clone() for st in optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
         import torch.distributed as dist
         self.pg = process_group
         nranks = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
@@ -268,6 +267,11 @@ class GraphedTrainStep:
             live = {id(p) for p in self._gp}
             self._ep_rest = [e for p, e in zip(self._mp, self._ep) if id(p) not in live]
             self._mp_rest = [p for p in self._mp if id(p) not in live]
+        # taken AFTER FusedAdamWEMA's constructor: it replaces a CPU / non-fp32 `step` counter of an optimizer that has already stepped
+        # by a device tensor of the same value -- a snapshot keyed by id() from before would miss the new tensor and the restore
+        # below would zero the bias-correction count
+        with torch.no_grad():
+            o_snap = {id(v): v.detach().clone() for st in optimizer.state.values() for v in st.values() if torch.is_tensor(v)}
         # Non-finite gradients (the reference's eager loop skips such a step, train.py:254-256): a replayed graph cannot branch on
         # the host, so the decision is taken ON THE DEVICE -- found_inf is computed from the (all-reduced, hence rank-identical)
         # gradients inside the graph and handed to the fused AdamW, which then leaves weights, moments and step count alone.

@@ -174,6 +174,9 @@ class DiffMa(nn.Module):
             else:
                 x = blk(outs[-1], c, w, **kw(i))
             outs.append(x)
+        if x.is_cuda and torch.cuda.is_current_stream_capturing():
+            from .block_ops import drop_mask_cache
+            drop_mask_cache()                          # the blocks' shared mask copy belongs to this capture's pool: not to the next one
         return self.unpatchify(self.final_layer(x, c))
 
     def forward_with_cfg(self, x, t, y, y2, w, cfg_scale):

@@ -26,6 +26,13 @@ from .step_prep import cast_weight, stacked_pair
 REPACK_OWN = os.environ.get("DIFFMA_REPACK_OWN", "1") == "1"        # 0: the ATen strided copy again (A/B runs)
 
 
+def _repack_own(t: torch.Tensor) -> bool:
+    """dm_repack takes the tensor: a contiguous-last-axis 3-d device tensor of a supported dtype whose batch fits the launch grid's
+    z extent (65 535; larger stacked batches keep the ATen strided copy, which has no such limit)."""
+    return (REPACK_OWN and t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.shape[0] <= 65535
+            and t.dtype in (torch.float32, torch.bfloat16, torch.float16))
+
+
 def _to_token_major(t: torch.Tensor) -> torch.Tensor:
     """(B, D, L) in any layout -> a [B, L, D] tensor with stride(-1) == 1 (no copy when possible; a genuinely L-contiguous
     tensor -- what the reference hands over, block/mamba.py:333-348 -- goes through dm_repack).  No autograd: callers are
@@ -33,7 +40,7 @@ def _to_token_major(t: torch.Tensor) -> torch.Tensor:
     tm = t.transpose(1, 2)
     if tm.stride(-1) == 1:
         return tm
-    if REPACK_OWN and t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):
+    if _repack_own(t):
         return hip_ops.repack(t, True)
     return tm.contiguous()
 
@@ -42,7 +49,7 @@ def _to_channel_major(t: torch.Tensor) -> torch.Tensor:
     """[B, L, D] token-major -> a CONTIGUOUS (B, D, L) tensor (the layout the reference's glue goes on with: CrossScan.backward,
     the in_proj gradient products, block/mamba.py:47-57, 333-337); a lazily transposed view would make every consumer a
     strided ATen copy."""
-    if REPACK_OWN and t.is_cuda and t.dim() == 3 and t.stride(2) == 1 and t.dtype in (torch.float32, torch.bfloat16, torch.float16):
+    if _repack_own(t):
         return hip_ops.repack(t, False)
     return t.transpose(1, 2).contiguous()
 

@@ -41,6 +41,8 @@ def invalidate():
     re-casts the masters and cast_weight() falls back to a fresh cast until it has (before this an eager grad-enabled
     forward after a replay multiplied by weight copies one optimizer step old)."""
     _GEN[0] += 1
+    from .block_ops import drop_mask_cache
+    drop_mask_cache()
 
 
 class _NegExpAll(torch.autograd.Function):

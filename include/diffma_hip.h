@@ -88,7 +88,8 @@ enum {
  *                       and grad[b] = (d mse_b / d eps | d vb_b / d v), fp32 [batch][2 channels][hw]
  *   dm_training_loss_bwd  grad_out (model output dtype) = (g_eps[b] * grad[b, :C] | g_v[b] * grad[b, C:])
  * model_out: [batch][2 channels][hw] contiguous (eps | variance logits), dtype out_dtype; x_start, x_t, noise fp32 [batch][channels][hw];
- * t int64 [batch]; tables fp32 [nrows][T] with the row numbers of sqrt(abar), sqrt(1 - abar), log(posterior variance, clipped),
+ * t int64 [batch], PRECONDITION 0 <= t[b] < T (a timestep outside the range reads no table entry: that sample's x_t / mse / vb / loss /
+ * grad come back NaN, which the training loop's non-finite guard then reports); tables fp32 [nrows][T] with the row numbers of sqrt(abar), sqrt(1 - abar), log(posterior variance, clipped),
  * log(beta), sqrt(1 / abar), sqrt(1 / abar - 1), posterior mean coefficients 1 and 2.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct {
@@ -735,7 +736,7 @@ int dm_gemm_supported(int P, int Q, int Kc, int a_kmajor, int b_kmajor, int ab_d
  * 16-bit C of the operand dtype, no accumulation.  Replaces the library (hipBLASLt through F.linear / torch.mm) GEMMs of
  * in_proj / out_proj (reference block/mamba.py:261,315,333-337) and of their input gradients (through a transposed 16-bit copy
  * of the weight) at M = B L >= 2048 rows: a persistent 256 x 256 tile kernel whose operand stream and C-tile stores run across
- * tile boundaries (the contraction is only 512 .. 2048 long).  P >= 2048, Q % 256 == 0, Kc % 128 == 0; strides as dm_gemm,
+ * tile boundaries (the contraction is only 512 .. 2048 long).  P >= 2048, Q % 256 == 0, Kc >= 512 and Kc % 512 == 0 (the unrolled body is 16 K-steps of 32); strides as dm_gemm,
  * ldc % 8 == 0; every tensor below 2 GB.  dm_gemm_large_supported answers for a shape without launching.
  * ---------------------------------------------------------------------------------------------- */
 int dm_gemm_large(const dm_gemm_args *args, void *stream);

@@ -578,3 +578,51 @@ def test_adaln_stack_is_the_blocks_shadows_and_one_product_equals_sixteen():
     torch.testing.assert_close(st2[0][1].float(), ws[1].detach().to(dt).float())
     torch.testing.assert_close(st[0][1].float(), (ws[1].detach() - 1.0).to(dt).float(), rtol=1e-2, atol=1e-2)     # what `held` saw
     del held
+
+
+def test_bench_launch_plan_self_launches_for_several_gpus():
+    """`python bench.py --gpus N` outside torch.distributed.run must re-execute itself under it (reference train.py:153,190 is
+    started by torchrun), and say what is wrong -- not assert -- when the node has fewer GPUs or the launcher disagrees."""
+    import bench
+
+    argv = ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert bench.launch_plan(1, {}, 0, []) == ("run", None)
+    assert bench.launch_plan(1, {}, 8, ["--gpus", "1"]) == ("run", None)
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, 8, argv) == ("run", None)          # already a rank: the driver's launch
+    act, msg = bench.launch_plan(2, {}, 1, ["--gpus", "2"])
+    assert act == "error" and "2 GPUs requested, 1 visible" in msg
+    act, msg = bench.launch_plan(8, {"WORLD_SIZE": "4"}, 8, argv)
+    assert act == "error" and "WORLD_SIZE=4" in msg
+    act, cmd = bench.launch_plan(8, {}, 8, argv)
+    assert act == "relaunch"
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                                        # the user's own arguments travel unchanged
+
+
+def test_bench_without_enough_gpus_fails_with_a_message_not_an_assert():
+    """On this GPU-less container `--gpus 2` has to end with exit code 2 and the message on stderr (the first 8-GPU run of the
+    driver must produce either a number or a readable reason)."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    assert r.returncode == 2, r.stderr[-500:]
+    assert f"2 GPUs requested, {torch.cuda.device_count()} visible" in r.stderr and "AssertionError" not in r.stderr
+    assert r.stdout.strip() == ""                                     # no half-written JSON line
+
+
+def test_bench_leg_specs_cover_the_baseline_configs():
+    import bench
+
+    assert set(bench.LEG_SPECS) == {"c2", "c4", "c5", "c3_one_sample_graph"}
+    a = bench.parse([])
+    for name, spec in bench.LEG_SPECS.items():
+        for k in spec:
+            assert k == "what" or hasattr(a, k), (name, k)            # every override names a real bench argument
+    assert bench.LEG_SPECS["c4"]["use_mamba2"] and bench.LEG_SPECS["c5"]["sampler"] == "ddim50" and bench.LEG_SPECS["c2"]["model"] == "DiffMa-B/4"
