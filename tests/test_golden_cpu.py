@@ -430,6 +430,65 @@ def test_oracle_mamba2_combined_matches_reference_step(tag):
     assert err <= 1e-9, f"oracle Mamba-2 operator vs reference Mamba2.step(): max abs {err}"
 
 
+# ---- G10 fd: the BACKWARD pinned to reference-held arithmetic.  tools/gen_golden.py differences the reference's own step() loops
+# (fp64 central differences of f = <out, dy>, eps 1e-6, along 8 random {-1, 0, +1} directions in (hidden, every parameter); A_log,
+# which step() rounds to fp32, along 2 directions with fp32-exact steps 2^-5 / 2^-6 and Richardson extrapolation).  The oracle's
+# autograd gradient contracted with each direction has to match: <= 1e-8 of the contraction's own magnitude sum |grad . dir| (measured: <= 8e-12).
+def _fd_check(tag, f_of, names, tensors, e, A_log):
+    dy = torch.from_numpy(e["fd.dy"])
+    leaves = [t.clone().requires_grad_(True) for t in tensors]
+    a_leaf = A_log.clone().requires_grad_(True)
+    out = f_of(dict(zip(names, leaves)), -torch.exp(a_leaf.float()).double())      # the reference's own rounding of A_log (block/mamba.py:431)
+    grads = torch.autograd.grad((out * dy).sum(), leaves + [a_leaf])
+    worst = 0.0
+    for j in range(8):
+        got = sum(float((gr * torch.from_numpy(e[f"fd.dir{j}.{n}"].astype(np.float64))).sum()) for n, gr in zip(names, grads))
+        mag = sum(float((gr * torch.from_numpy(e[f"fd.dir{j}.{n}"].astype(np.float64))).abs().sum()) for n, gr in zip(names, grads))
+        want = float(e[f"fd.val{j}"])
+        worst = max(worst, abs(got - want) / mag)
+        assert abs(got - want) <= 1e-8 * mag, f"{tag} direction {j}: oracle autograd {got} vs reference finite difference {want} (scale {mag})"
+    for j in range(2):
+        d = torch.from_numpy(e[f"fd.dirA{j}"].astype(np.float64))
+        got, mag, want = float((grads[-1] * d).sum()), float((grads[-1] * d).abs().sum()), float(e[f"fd.valA{j}"])
+        # looser: step() evaluates exp(A_log) in fp32 (block/mamba.py:431, block/mamba2.py:741); that rounding (6e-8 of A) is amplified
+        # by 1 / h in any difference quotient -- ~1e-5 of the derivative at these steps, with only nheads entries to average over for Mamba-2
+        worst_a = abs(got - want) / max(mag, 1e-300)
+        assert abs(got - want) <= 5e-5 * mag + 1e-12, f"{tag} A_log direction {j}: {got} vs {want} (scale {mag}, rel {worst_a:.2e})"
+    return worst
+
+
+@pytest.mark.parametrize("tag", G10_M1)
+def test_oracle_mamba_inner_backward_matches_reference_step_finite_differences(tag):
+    from oracle.mamba_ref import mamba_inner_ref
+
+    sd, e = g10_case(tag)
+    names = ["hidden"] + [k for k in sd if k != "A_log"]
+    tensors = [torch.from_numpy(e["hidden"])] + [sd[k] for k in names[1:]]
+
+    def f_of(p, A):
+        xz = torch.einsum("ed,bld->bel", p["in_proj.weight"], p["hidden"])
+        return mamba_inner_ref(xz, p["conv1d.weight"], p["conv1d.bias"], p["x_proj.weight"], p["dt_proj.weight"], p["out_proj.weight"], None,
+                               A, None, None, p["D"], delta_bias=p["dt_proj.bias"], delta_softplus=True)
+    _fd_check(tag, f_of, names, tensors, e, torch.from_numpy(e["fd.A_log"]))
+
+
+@pytest.mark.parametrize("tag", G10_M2)
+def test_oracle_mamba2_combined_backward_matches_reference_step_finite_differences(tag):
+    from oracle.mamba2_ref import mamba_split_conv1d_scan_combined_ref
+
+    sd, e = g10_case(tag)
+    rms = bool(int(e["rmsnorm"]))
+    names = ["hidden"] + [k for k in sd if k != "A_log"]
+    tensors = [torch.from_numpy(e["hidden"])] + [sd[k] for k in names[1:]]
+
+    def f_of(p, A):
+        return mamba_split_conv1d_scan_combined_ref(
+            p["hidden"] @ p["in_proj.weight"].t(), p["conv1d.weight"], p["conv1d.bias"], p["dt_bias"], A, p["D"], chunk_size=256,
+            activation="silu", rmsnorm_weight=p["norm.weight"] if rms else None, rmsnorm_eps=1e-5, outproj_weight=p["out_proj.weight"],
+            outproj_bias=None, headdim=int(e["headdim"]), ngroups=1, norm_before_gate=False)
+    _fd_check(tag, f_of, names, tensors, e, torch.from_numpy(e["fd.A_log"]))
+
+
 # ---- G8b: CT_Encoder with the reference's shipped weights (pretrain_ct_vision_embedder/*.pt, "ema" entry, train.py:166-168) ----
 @pytest.mark.parametrize("name", ["brain", "pelvis"])
 def test_ct_encoder_loads_reference_pretrained_weights(name):

@@ -9,6 +9,7 @@ The OPERATOR arithmetic is pinned by G10: the reference's own pure-PyTorch Mamba
 recurrences (block/mamba.py:405-448, block/mamba2.py:715-775) run token by token.
 No reference source is copied: the fixtures are inputs and outputs only.
 """
+import copy
 import hashlib
 import os
 import sys
@@ -141,6 +142,62 @@ def main():
     # `selective_state_update` are None -- which is what the stubs above install.  Run token by token from zero states in fp64,
     # the stacked outputs are what mamba_inner_fn / mamba_split_conv1d_scan_combined must produce on the whole sequence: this
     # pins the oracle's OPERATOR arithmetic to reference-held code (no oracle function is involved in producing G10).
+    # The BACKWARD pinned to reference-held arithmetic (round-6 addition): step() cannot be back-propagated (in-place copy_ on the
+    # states), but it can be differenced.  For every G10 case: a fixed cotangent dy, the scalar f = <out, dy> of the reference's own
+    # token-by-token loop, and its fp64 CENTRAL finite differences (eps = 1e-6) along 8 random directions in the joint space of
+    # (hidden, every parameter except A_log), entries in {-1, 0, +1} (stored as int8).  A_log goes through `.float()` inside step()
+    # (block/mamba.py:431, block/mamba2.py:741), so a 1e-6 step would be rounded away: its two directions use steps that fp32
+    # holds exactly -- A_log is first rounded to a multiple of 2^-16 (`fd.A_log`, used for ALL fd values of the case), steps 2^-5 and
+    # 2^-6, Richardson-extrapolated ((4 D(h/2) - D(h)) / 3, error O(h^4)); what bounds their resolution is the fp32 exp inside step()
+    # (relative rounding 6e-8 of A, amplified by 1 / h: ~1e-5 of the derivative), hence the large steps and the looser bound in the test.  tests/test_golden_cpu.py contracts the oracle's autograd
+    # gradient with each direction and compares.
+    def fd_pin(m, run, hidden, tag, g, seed):
+        fgen = torch.Generator().manual_seed(seed)
+        with torch.no_grad():         # `m` is the caller's private deep copy: the G10 tensors proper are never touched
+            m.A_log.copy_(torch.round(m.A_log * 65536.0) / 65536.0)
+            out0 = run(hidden)
+        dy = torch.randn(out0.shape, generator=fgen, dtype=torch.float64)
+        params = {k: v for k, v in m.named_parameters() if k != "A_log"}
+        tri = lambda shape: (torch.randint(0, 3, tuple(shape), generator=fgen) - 1)
+        f = lambda h: float((run(h) * dy).sum())
+        g[f"{tag}.fd.A_log"] = m.A_log.detach().numpy().copy()
+        g[f"{tag}.fd.dy"] = dy.numpy()
+        eps = 1e-6
+        for j in range(8):
+            dirs = {k: tri(v.shape) for k, v in params.items()}
+            dh = tri(hidden.shape)
+            vals = []
+            for sgn in (+1.0, -1.0):
+                with torch.no_grad():
+                    for k, v in params.items():
+                        v.add_(dirs[k].double(), alpha=sgn * eps)
+                    vals.append(f(hidden + sgn * eps * dh.double()))
+                    for k, v in params.items():
+                        v.add_(dirs[k].double(), alpha=-sgn * eps)
+            g[f"{tag}.fd.val{j}"] = np.asarray((vals[0] - vals[1]) / (2 * eps))
+            g[f"{tag}.fd.dir{j}.hidden"] = dh.numpy().astype(np.int8)
+            for k, d_ in dirs.items():
+                g[f"{tag}.fd.dir{j}.{k}"] = d_.numpy().astype(np.int8)
+        for j in range(2):
+            dA = tri(m.A_log.shape)
+            if not bool(dA.any()):
+                dA = torch.ones_like(dA)
+            D = []
+            for h in (2.0 ** -5, 2.0 ** -6):
+                vals = []
+                for sgn in (+1.0, -1.0):
+                    with torch.no_grad():
+                        m.A_log.add_(dA.double(), alpha=sgn * h)
+                        assert torch.equal(m.A_log.float().double(), m.A_log)      # the step survives step()'s fp32 rounding exactly
+                        vals.append(f(hidden))
+                        m.A_log.add_(dA.double(), alpha=-sgn * h)
+                D.append((vals[0] - vals[1]) / (2 * h))
+            g[f"{tag}.fd.valA{j}"] = np.asarray((4.0 * D[1] - D[0]) / 3.0)
+            g[f"{tag}.fd.valA{j}.coarse"] = np.asarray(D[0])
+            g[f"{tag}.fd.dirA{j}"] = dA.numpy().astype(np.int8)
+        print("G10 fd", tag, "f", f(hidden), "vals", [float(g[f"{tag}.fd.val{j}"]) for j in range(3)], "valA", float(g[f"{tag}.fd.valA0"]),
+              "(coarse", float(g[f"{tag}.fd.valA0.coarse"]), ")")
+
     def g10():
         from block.mamba import Mamba as RefMamba
         from block.mamba2 import Mamba2 as RefMamba2
@@ -171,6 +228,19 @@ def main():
             g.update({f"{tag}.hidden": hidden.numpy(), f"{tag}.out": out.numpy(), f"{tag}.last_state": ssm_state.numpy(),
                       f"{tag}.A": (-torch.exp(m.A_log.detach().float())).numpy()})
             print("G10", tag, "out abs mean", float(out.abs().mean()))
+
+            mfd = copy.deepcopy(m)
+
+            def run1(h, m=mfd, Bsz=Bsz, L=L):
+                cs = torch.zeros(Bsz, m.d_inner, m.d_conv, dtype=torch.float64)
+                ss = torch.zeros(Bsz, m.d_inner, m.d_state, dtype=torch.float64)
+                o_ = []
+                with torch.no_grad():
+                    for l in range(L):
+                        o, cs, ss = m.step(h[:, l:l + 1], cs, ss)
+                        o_.append(o)
+                return torch.cat(o_, dim=1)
+            fd_pin(mfd, run1, hidden, tag, g, 7000 + L + dm)
         # Mamba-2: rmsnorm=False is held by the reference end to end (gate = y * silu(z), block/mamba2.py:758-759); with
         # rmsnorm=True the reference calls the absent wheel's RMSNormGated (block/mamba2.py:771), here given the documented
         # forward of that class for norm_before_gate=False: rmsnorm(y * silu(z)) * weight -- conv, recurrence and D skip are
@@ -206,6 +276,19 @@ def main():
             g.update({f"{tag}.hidden": hidden.numpy(), f"{tag}.out": out.numpy(), f"{tag}.headdim": np.asarray(hd),
                       f"{tag}.rmsnorm": np.asarray(int(rms)), f"{tag}.A": (-torch.exp(m.A_log.detach().float())).numpy()})
             print("G10", tag, "out abs mean", float(out.abs().mean()))
+
+            mfd = copy.deepcopy(m)
+
+            def run2(h, m=mfd, Bsz=Bsz, L=L, conv_dim=conv_dim):
+                cs = torch.zeros(Bsz, conv_dim, m.d_conv, dtype=torch.float64)
+                ss = torch.zeros(Bsz, m.nheads, m.headdim, m.d_state, dtype=torch.float64)
+                o_ = []
+                with torch.no_grad():
+                    for l in range(L):
+                        o, cs, ss = m.step(h[:, l:l + 1], cs, ss)
+                        o_.append(o)
+                return torch.cat(o_, dim=1)
+            fd_pin(mfd, run2, hidden, tag, g, 8000 + L + dm + hd)
         np.savez_compressed(os.path.join(OUT, "g10_reference_step.npz"), **g)
 
     # ---- G8b CT_Encoder with the reference's SHIPPED weights (pretrain_ct_vision_embedder/*.pt, loaded the way train.py:166-168
