@@ -35,6 +35,9 @@
 #include <type_traits>
 #include "dm_common.h"
 
+#ifndef DM_K2_HALVES
+#define DM_K2_HALVES 1         // developer A/B: 0 = the whole channel's 16 states in one pass (rounds 3-5)
+#endif
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
 #endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
@@ -153,6 +156,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     constexpr int NS = N / SPLIT, NPL = NS / 2, CW = WAVE / SPLIT, CK = BWD_CK, SUB = BWD_SUB, M = 2 * NS, R = M / 4;
     constexpr int ES = (int)sizeof(T);
     constexpr bool MFMA_RED = std::is_same<T, bf16_t>::value && M % 16 == 0;   // dB/dC lane-group sums on the matrix pipe
+    // HALVES: the lane's 16 states as two groups of 8 walked one after the other, the recomputed steps' decay factors reused by the sweep
+    constexpr bool HALVES = (DM_K2_HALVES != 0) && MFMA_RED && SPLIT == 1 && N == 16;
+    constexpr int NH = HALVES ? 2 : 1, NPH = NPL / NH;
+    constexpr bool CACHE_A = HALVES && !ASH;
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
@@ -272,8 +279,11 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
                 acc4[i] = v;
             }
-            const float mine = tq == 0 ? acc4[0] : (tq == 1 ? acc4[1] : (tq == 2 ? acc4[2] : acc4[3]));             // output 4 g4 + tq of step j
-            const int vo_p = (l0 + j < L) ? (((l0 + j) * nwg + (int)blockIdx.x) * (2 * N) + 4 * g4 + tq) * 4 : BIO_OOB;
+            const float mine = tq == 0 ? acc4[0] : (tq == 1 ? acc4[1] : (tq == 2 ? acc4[2] : acc4[3]));             // value 4 g4 + tq of step j
+            // whole-channel form: value V = column V of [dB 0..15 | dC 0..15].  HALVES: LDS group hf = V >> 4 holds [dB 8hf..8hf+7 | dC 8hf..8hf+7]
+            const int V = 4 * g4 + tq;
+            const int col = HALVES ? ((V & 8) ? N + 8 * (V >> 4) + (V & 7) : 8 * (V >> 4) + (V & 7)) : V;
+            const int vo_p = (l0 + j < L) ? (((l0 + j) * nwg + (int)blockIdx.x) * (2 * N) + col) * 4 : BIO_OOB;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mine), r_dbc, vo_p, 0, 0);
             return;
         }
@@ -323,15 +333,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
         }
     };
-    auto unpack_state = [&](f32x2(&h)[NPL], const uint32_t(&w)[H0W]) {
+    auto unpack_state = [&](f32x2(&h)[NPH], const uint32_t(&w)[H0W], int hf) {       // group hf of the slice: pairs hf*NPH ..
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
+        for (int k = 0; k < NPH; ++k) {
+            const int kk = hf * NPH + k;
             if constexpr (CK_PACKED) {
-                h[k].x = __uint_as_float(w[k] << 16);
-                h[k].y = __uint_as_float(w[k] & 0xffff0000u);
+                h[k].x = __uint_as_float(w[kk] << 16);
+                h[k].y = __uint_as_float(w[kk] & 0xffff0000u);
             } else {
-                h[k].x = __uint_as_float(w[2 * k]);
-                h[k].y = __uint_as_float(w[2 * k + 1]);
+                h[k].x = __uint_as_float(w[2 * kk]);
+                h[k].y = __uint_as_float(w[2 * kk + 1]);
             }
         }
     };
@@ -346,19 +357,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     static_assert(SUB == 4, "row-table entries of a sub-chunk travel as one 4-dword scalar load");
     constexpr int NSC = CK / SUB;
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
-    typedef const i32x4_t __attribute__((address_space(4), aligned(4)))* idx4_ptr;
+    // Four single scalar loads per table and sub-chunk, addresses clamped to the last row, no branch.  (Until round 6 a 4-dword load
+    // for whole sub-chunks and the four single loads for the ragged tail were BOTH issued -- hipcc if-converts the choice -- into the
+    // same SGPR quad: the write-after-write hazard put an `s_waitcnt lgkmcnt(0)` right behind the first load, a full scalar-memory
+    // latency per table and sub-chunk with the whole wave parked; writing the choice as a real branch parks it at the join instead.)
     auto load_rows = [&](cptr<int32_t> tab, int ci) -> i32x4_t {          // rows of the steps of sub-chunk ci (clamped to L - 1)
-        const int lb = ci * SUB;
+        const int lb = ci < 0 ? 0 : ci * SUB;
         i32x4_t r = {0, 0, 0, 0};
-        if (ci < 0) return r;
-        if (IDX && lb + SUB <= L) {
-            r = *(idx4_ptr)(tab + lb);
-        } else {
 #pragma unroll
-            for (int i = 0; i < SUB; ++i) {
-                const int l = (lb + i < L) ? lb + i : L - 1;
-                r[i] = IDX ? tab[l] : l;
-            }
+        for (int i = 0; i < SUB; ++i) {
+            const int l = (lb + i < L) ? lb + i : L - 1;
+            r[i] = IDX ? tab[l] : l;
         }
         return r;
     };
@@ -416,45 +425,54 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             // ---- request the next one (ci - 1): lands while this one computes
             zrow_nx = zrow_is;
             issue_sub(ci - 1);                  // (ci = 0: rows 0 and an out-of-range checkpoint -- harmless, and no branch)
-            // one forward step of the slice: h <- a*h + B*dl*u
-            auto fwd_step = [&](f32x2(&h)[NPL], int i) {
-                float Bv[NS];
-                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + sc * SUB + i) * 2 * N + q * NS);   // re-read, do not keep rows in VGPRs
-                if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) Bv[k] = opaque(1.0f); } else
-                lds_ld_vec<NS>(Bv, brow);
-                const float dlo = opaque(dl[i]);
+            // Halves in sequence (round 6; HALVES): the lane walks its channel's states in NH groups of NPH pairs, one after the other,
+            // over the SAME sub-chunk -- inputs, conversions, softplus', the stores and every per-channel scalar are issued once, the
+            // recomputed states of only one group are live (hs: 32 instead of 64 registers), and the registers that frees hold the decay
+            // factors a = exp2(A2 dl) of the three recomputed steps, which the reverse sweep then REUSES instead of evaluating them again
+            // (28 -> 16 v_exp_f32 and 6 packed multiplies less per wave-step).  The per-step sums over the states (G.B, A.Gt, C.h) are
+            // carried from group to group in GB2s / dlA2s / yp2s; the step's outputs are formed and stored in the last group's sweep.
+            f32x2 GB2s[SUB], dlA2s[SUB], yp2s[HAS_Z ? SUB : 1];
+#pragma unroll
+            for (int hf = 0; hf < NH; ++hf) {
+            // one forward step of the group: h <- a*h + B*dl*u   (a kept in `keep` when the sweep will reuse it)
+            auto fwd_step = [&](f32x2(&h)[NPH], int i, f32x2(&keep)[NPH]) {
+                float Bv[2 * NPH];
+                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + sc * SUB + i) * 2 * N + q * NS + hf * 2 * NPH);   // re-read, do not keep rows in VGPRs
+                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) Bv[k] = opaque(1.0f); } else
+                lds_ld_vec<2 * NPH>(Bv, brow);
+                const float dlo = CACHE_A ? dl[i] : opaque(dl[i]);
                 const float du = dlo * uu[i];
                 float a_sh = 0.f;
                 if (ASH) a_sh = fast_exp2(A2[0].x * dlo);             // DM_FLAG_A_SHARED: one decay factor for all states of the channel
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) {
+                for (int k = 0; k < NPH; ++k) {
                     f32x2 a;
                     if (ASH) {
                         a = (f32x2){a_sh, a_sh};
                     } else {
-                        const f32x2 t = A2[k] * dlo;
+                        const f32x2 t = A2[hf * NPH + k] * dlo;
                         a.x = fast_exp2(t.x);
                         a.y = fast_exp2(t.y);
                     }
+                    if (CACHE_A) keep[k] = a;
                     f32x2 bb;
                     bb.x = Bv[2 * k];
                     bb.y = Bv[2 * k + 1];
                     h[k] = a * h[k] + bb * du;
                 }
             };
-            f32x2 h[NPL];
-            unpack_state(h, ck_cur);
-            f32x2 hs[SUB][NPL];                                          // hs[i] = state before step sc*SUB+i
+            f32x2 h[NPH];
+            unpack_state(h, ck_cur, hf);
+            f32x2 hs[SUB][NPH];                                          // hs[i] = state before step sc*SUB+i
+            f32x2 aa[CACHE_A ? SUB - 1 : 1][NPH];                        // decay factors of the recomputed steps
 #pragma unroll
             for (int i = 0; i < SUB; ++i) {
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) hs[i][k] = h[k];
-                if (i < SUB - 1) fwd_step(h, i);
+                for (int k = 0; k < NPH; ++k) hs[i][k] = h[k];
+                if (i < SUB - 1) fwd_step(h, i, aa[CACHE_A ? i : 0]);
             }
             // the state after the sub-chunk's last step is the checkpoint of the sub-chunk processed before: one recomputed step less
-            unpack_state(h, ck_end);
-#pragma unroll
-            for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];
+            unpack_state(h, ck_end, hf);
             // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
 #pragma unroll
             for (int i = SUB - 1; i >= 0; --i) {
@@ -462,53 +480,57 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const int lraw = l0 + j;
                 const bool valid = lraw < L;                    // wave-uniform
                 const int l = valid ? lraw : L - 1;
-                float Bv[NS], Cv[NS];
-                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS);
-                if (DM_K2_EXP & 16) { for (int k = 0; k < NS; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
-                lds_ld_vec<NS>(Bv, brow);
-                lds_ld_vec<NS>(Cv, brow + N); }
+                float Bv[2 * NPH], Cv[2 * NPH];
+                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS + hf * 2 * NPH);
+                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
+                lds_ld_vec<2 * NPH>(Bv, brow);
+                lds_ld_vec<2 * NPH>(Cv, brow + N); }
                 const float g = gg[i];
                 float sz = 1.f, gy = g;
                 if (HAS_Z) {
                     sz = sigmoid_f(zz[i]);
                     gy = g * zz[i] * sz;
                 }
-                const float dlo = opaque(dl[i]);
+                const float dlo = (CACHE_A && i < SUB - 1) ? dl[i] : opaque(dl[i]);
                 const float du = dlo * uu[i];
                 float a_rev = 0.f;
                 if (ASH) a_rev = fast_exp2(A2[0].x * dlo);
                 f32x2 yp2 = (f32x2){0.f, 0.f}, GB2 = (f32x2){0.f, 0.f}, dlA2 = (f32x2){0.f, 0.f};
-                float red[M];
-                uint32_t pk_all[M / 2];                        // bf16 pairs: [dB pairs (NPL) | dC pairs (NPL)]
+                if (hf > 0) { GB2 = GB2s[i]; dlA2 = dlA2s[i]; if (HAS_Z) yp2 = yp2s[i]; }
+                float red[NH == 1 ? M : 1];
+                uint32_t pk_all[M / 2 / NH];                   // bf16 pairs: [dB pairs (NPH) | dC pairs (NPH)] of this group
 #pragma unroll
-                for (int k = 0; k < NPL; ++k) {
+                for (int k = 0; k < NPH; ++k) {
+                    const int kk = hf * NPH + k;               // the pair's place among the lane's NPL pairs
                     f32x2 bb, cc;
                     bb.x = Bv[2 * k]; bb.y = Bv[2 * k + 1];
                     cc.x = Cv[2 * k]; cc.y = Cv[2 * k + 1];
                     f32x2 a;
                     if (ASH) {
                         a = (f32x2){a_rev, a_rev};
+                    } else if (CACHE_A && i < SUB - 1) {
+                        a = aa[CACHE_A ? i : 0][k];
                     } else {
-                        const f32x2 t = A2[k] * dlo;
+                        const f32x2 t = A2[kk] * dlo;
                         a.x = fast_exp2(t.x);
                         a.y = fast_exp2(t.y);
                     }
                     const f32x2 hj = h[k];
                     const f32x2 hp = hs[i][k];
                     if (HAS_Z) yp2 += cc * hj;
-                    const f32x2 G = cc * gy + carry[k];          // dL/dh_j
+                    const f32x2 G = cc * gy + carry[kk];         // dL/dh_j
                     const f32x2 dCp = hj * gy;
-                    carry[k] = a * G;                            // a_j * dL/dh_j, flows to step j-1
-                    const f32x2 Gt = carry[k] * hp;              // = G * a * h_{j-1}
-                    dlA2 += A2[k] * Gt;
-                    dA[k] += Gt * dlo;
-                    dA[k].x = opaque(dA[k].x);                   // accumulate NOW: left alone the scheduler defers all 8 steps'
-                    dA[k].y = opaque(dA[k].y);                   // products to the chunk end and keeps 64 VGPRs alive for them
+                    carry[kk] = a * G;                           // a_j * dL/dh_j, flows to step j-1
+                    const f32x2 Gt = carry[kk] * hp;             // = G * a * h_{j-1}
+                    dlA2 += A2[kk] * Gt;
+                    dA[kk] += Gt * dlo;
+                    dA[kk].x = opaque(dA[kk].x);                 // accumulate NOW: left alone the scheduler defers all 8 steps'
+                    dA[kk].y = opaque(dA[kk].y);                 // products to the chunk end and keeps 64 VGPRs alive for them
                     GB2 += G * bb;
                     const f32x2 dBp = G * du;
                     if constexpr (MFMA_RED) {
                         pk_all[k] = pack_bf16(dBp.x, dBp.y);
-                        pk_all[NPL + k] = pack_bf16(dCp.x, dCp.y);
+                        pk_all[NPH + k] = pack_bf16(dCp.x, dCp.y);
                     } else {
                         red[2 * k] = dBp.x;
                         red[2 * k + 1] = dBp.y;
@@ -517,6 +539,8 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     }
                     h[k] = hp;
                 }
+                if (hf < NH - 1) { GB2s[i] = GB2; dlA2s[i] = dlA2; if (HAS_Z) yp2s[i] = yp2; }
+                if (hf == NH - 1) {
                 const float ypre = slice_sum<SPLIT>(yp2.x + yp2.y) + Dv * uu[i];
                 const float GB = slice_sum<SPLIT>(GB2.x + GB2.y);
                 const float dlA = slice_sum<SPLIT>(dlA2.x + dlA2.y);
@@ -536,10 +560,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                         bio<T>::st_cv(r_dz, vo_s, zrow[i] * sl_dz, dzv);
                     }
                 }
+                }
                 if constexpr (DM_K2_EXP & 1) {
                 } else if constexpr ((DM_K2_EXP & 32) != 0 && MFMA_RED) {       // products + conversions only: no MFMA, no LDS write (flush: bit 2)
 #pragma unroll
-                    for (int k = 0; k < M / 2; ++k) asm volatile("" ::"v"(pk_all[k]));
+                    for (int k = 0; k < M / 2 / NH; ++k) asm volatile("" ::"v"(pk_all[k]));
+                } else if constexpr (MFMA_RED && NH == 2) {
+                    // this group's 16 values (dB and dC of its 8 states) = ONE pair of MFMAs; LDS group hf (flush_dbc maps the columns)
+                    const u32x4_t lo = {pk_all[0], pk_all[1], pk_all[2], pk_all[3]};
+                    const u32x4_t hi = {pk_all[4], pk_all[5], pk_all[6], pk_all[7]};
+                    const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
+                    *reinterpret_cast<f32x4*>(&red_lds[wave][j][hf * RED_HALF + red_slot]) = dsum;
                 } else if constexpr (MFMA_RED) {
 #pragma unroll
                     for (int g16 = 0; g16 < M / 16; ++g16) {   // 16 values (8 pairs) per pair of MFMAs; register r of group g16 = value 16*g16 + 4*(lane>>4) + r
@@ -555,6 +586,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                         *reinterpret_cast<f32x4*>(&red_lds[wave][j][r4 * RED_HALF + red_slot]) = (f32x4){red[4 * r4], red[4 * r4 + 1], red[4 * r4 + 2], red[4 * r4 + 3]};
                 }
             }
+            }   // hf
+#pragma unroll
+            for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];
         }
         if (!(DM_K2_EXP & 2)) __syncthreads();
         if (!(DM_K2_EXP & 35)) flush_dbc(ch);

@@ -144,24 +144,83 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int hb = h * 64 * ES;                                                   // byte offset of the head's columns in a row
     float* const dbc_part = p.dBC_part + ((int64_t)h * p.nseq + s) * L * 32;          // head-major: the caller's sum over heads is a column sum
 
-    // ---- phase 0: per-position scalars (thread t <-> position t) ----------------------------------------------------------------
-    float dtv = 0.0f;
-    {
-        float sg = 0.0f;
-        int zr = 0, orow = 0;
-        if (tid < L) {
-            zr = zidx ? zidx[tid] : tid;
-            orow = oidx ? oidx[tid] : tid;
-            const float raw = io<T>::ld(dtp + (int64_t)zr * p.dt_sl) + bias;
-            dtv = softplus_f(raw);
-            sg = (raw > 20.0f) ? 1.0f : sigmoid_f(raw);                            // d softplus / d raw (identity above 20)
+    // ---- phases 0 + 1 (round 6): EVERY global load of the (sequence, head) is requested up front, in two dependent waves ----------
+    // Until round 6 the kernel walked a chain of ~6 memory latencies before its first MFMA (row indices -> dt -> [prefix sums] ->
+    // x / dout / z of chunk w -> the same of chunk w + 4 -> B / C half 0 -> half 1), each ended by LDS stores or a barrier, with only
+    // two workgroups per CU to cover for one another: 35 % of the wave-cycles parked at barriers, no unit busy
+    // (profiles/r05_m2_ssd_pmc.txt).  Now: level 1 = B / C, the x rows and the row-index entries (the thread's own position and the
+    // 4 rows the lane moves), level 2 = dt, dout, z through those indices -- 2 latencies; the tables are computed while level 2 flies.
+    // phase 1 role: wave w moves the 16-byte chunks w and w + 4 of every row; lane rows r = lane + 64 j
+    float dtv = 0.0f, sg0 = 0.0f;
+    int zr0 = 0, orow0 = 0;
+    ssd_u32x4 bq[2], cq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                                 // B / C: two 16-byte chunks per row, two rows per thread
+        const int e = tid + SB_THREADS * i;
+        const int r = e >> 1, hf = e & 1;
+        const int rc = r < L ? r : L - 1;
+        const auto b = __builtin_amdgcn_raw_buffer_load_b128(r_B, rc * sl_B + hf * 16, 0, 0);
+        const auto c = __builtin_amdgcn_raw_buffer_load_b128(r_C, rc * sl_C + hf * 16, 0, 0);
+        bq[i] = (ssd_u32x4){b[0], b[1], b[2], b[3]};
+        cq[i] = (ssd_u32x4){c[0], c[1], c[2], c[3]};
+    }
+    const int pc = tid < L ? tid : L - 1;
+    if (zidx) { zr0 = zidx[pc]; orow0 = oidx[pc]; } else { zr0 = pc; orow0 = pc; }
+    int zrow[4], drow[4];
+    ssd_u32x4 xq4[2][4], dq4[2][4], zq4[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = lane + 64 * j;
+        const int rc = r < L ? r : L - 1;
+        zrow[j] = zidx ? zidx[rc] : rc;
+        drow[j] = oidx ? oidx[rc] : rc;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, rc * sl_x + hb + (w + 4 * m) * 16, 0, 0);
+            xq4[m][j] = (ssd_u32x4){xq[0], xq[1], xq[2], xq[3]};
         }
-        if (tid < SB_TAB) {
-            DT[tid] = dtv;
-            SIG[tid] = sg;
-            zi[tid] = (uint16_t)zr;
-            oi[tid] = (uint16_t)orow;
+    }
+    // level 2: through the indices
+    float rawv = 0.0f;
+    if (tid < L) rawv = io<T>::ld(dtp + (int64_t)zr0 * p.dt_sl);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int cb = hb + (w + 4 * m) * 16;
+            const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, drow[j] * sl_do + cb, 0, 0);
+            dq4[m][j] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
+            zq4[m][j] = (ssd_u32x4){0u, 0u, 0u, 0u};
+            if (p.z) {
+                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, zrow[j] * sl_z + cb, 0, 0);
+                zq4[m][j] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
+            }
         }
+    // B / C into LDS (level 1 has landed by the time the dt value is needed)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + SB_THREADS * i;
+        const int r = e >> 1, hf = e & 1;
+        if (r < SB_ROWS) {
+            const ssd_u32x4 zero4 = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<ssd_u32x4*>(lds + SB_BS + r * 32 + hf * 16) = r < L ? bq[i] : zero4;
+            *reinterpret_cast<ssd_u32x4*>(lds + SB_CS + r * 32 + hf * 16) = r < L ? cq[i] : zero4;
+        }
+    }
+    // per-position scalars (thread t <-> position t)
+    if (tid < L) {
+        const float raw = rawv + bias;
+        dtv = softplus_f(raw);
+        sg0 = (raw > 20.0f) ? 1.0f : sigmoid_f(raw);                               // d softplus / d raw (identity above 20)
+    } else {
+        zr0 = 0;
+        orow0 = 0;
+    }
+    if (tid < SB_TAB) {
+        DT[tid] = dtv;
+        SIG[tid] = sg0;
+        zi[tid] = (uint16_t)zr0;
+        oi[tid] = (uint16_t)orow0;
     }
     {
         const float c = block_prefix_sum(dtv, lane, w, red);                       // cumsum(dt)
@@ -182,34 +241,18 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     }
     auto m_of = [&](int t) -> float { return t ? S2[SB_TILE * t - 1] : 0.0f; };   // log-decay just before tile t
 
-    // ---- phase 1: X, gY = dout .* silu(z), B, C into LDS; wave w moves the 16-byte chunks w and w + 4 of every row --------------
+    // X, gY = dout .* silu(z) into LDS
     float dD_acc = 0.0f;
-#pragma unroll 1
+#pragma unroll
     for (int m = 0; m < 2; ++m) {
         const int ck = w + 4 * m;
-        const int cb = hb + ck * 16;
-        ssd_u32x4 xq4[4], dq4[4], zq4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                                             // 12 loads in flight before the first use
-            const int r = lane + 64 * j;
-            const int rc = r < L ? r : L - 1;
-            const auto xq = __builtin_amdgcn_raw_buffer_load_b128(r_x, rc * sl_x + cb, 0, 0);
-            const auto dq = __builtin_amdgcn_raw_buffer_load_b128(r_do, (int)oi[rc] * sl_do + cb, 0, 0);
-            xq4[j] = (ssd_u32x4){xq[0], xq[1], xq[2], xq[3]};
-            dq4[j] = (ssd_u32x4){dq[0], dq[1], dq[2], dq[3]};
-            zq4[j] = (ssd_u32x4){0u, 0u, 0u, 0u};
-            if (p.z) {
-                const auto v = __builtin_amdgcn_raw_buffer_load_b128(r_z, (int)zi[rc] * sl_z + cb, 0, 0);
-                zq4[j] = (ssd_u32x4){v[0], v[1], v[2], v[3]};
-            }
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = lane + 64 * j;
             if (r < SB_ROWS) {
                 ssd_u32x4 xv = {0u, 0u, 0u, 0u}, gv = {0u, 0u, 0u, 0u};
                 if (r < L) {
-                    const ssd_u32x4 xq = xq4[j], dq = dq4[j], zq = zq4[j];
+                    const ssd_u32x4 xq = xq4[m][j], dq = dq4[m][j], zq = zq4[m][j];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
                         float g0 = O::lo(dq[d]), g1 = O::hi(dq[d]);
@@ -226,22 +269,6 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 *reinterpret_cast<ssd_u32x4*>(lds + SB_XS + so) = xv;
                 *reinterpret_cast<ssd_u32x4*>(lds + SB_GS + so) = gv;
             }
-        }
-    }
-#pragma unroll 1
-    for (int i = 0; i < 2; ++i) {                                                 // B / C: two 16-byte chunks per row
-        const int e = tid + SB_THREADS * i;
-        const int r = e >> 1, hf = e & 1;
-        if (r < SB_ROWS) {
-            ssd_u32x4 bv = {0u, 0u, 0u, 0u}, cv = {0u, 0u, 0u, 0u};
-            if (r < L) {
-                const auto b = __builtin_amdgcn_raw_buffer_load_b128(r_B, r * sl_B + hf * 16, 0, 0);
-                const auto c = __builtin_amdgcn_raw_buffer_load_b128(r_C, r * sl_C + hf * 16, 0, 0);
-                bv = (ssd_u32x4){b[0], b[1], b[2], b[3]};
-                cv = (ssd_u32x4){c[0], c[1], c[2], c[3]};
-            }
-            *reinterpret_cast<ssd_u32x4*>(lds + SB_BS + r * 32 + hf * 16) = bv;
-            *reinterpret_cast<ssd_u32x4*>(lds + SB_CS + r * 32 + hf * 16) = cv;
         }
     }
     __syncthreads();

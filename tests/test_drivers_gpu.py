@@ -50,12 +50,22 @@ def _g5(gpu):
     return g, sd, net, inp
 
 
-def _oracle_denoiser(sd, patch, depth):
+def _oracle_denoiser(sd, patch, depth, compute_device=None):
+    """The fp64 oracle denoiser as a `model(x, t, **kw)` callable.  compute_device: run the oracle's torch code there (ATen's fp64
+    kernels on the GPU instead of seconds of host time per call) -- inputs are moved over and the result comes back on x's device, so
+    the sampling LOOP around it still runs on the host, through the generic (non-fused) diffusion arithmetic."""
     from oracle.model_ref import diffma_forward_ref
 
+    if compute_device is not None and os.environ.get("DIFFMA_TEST_ORACLE_ON_HOST") != "1":
+        sd = {k: v.to(compute_device) for k, v in sd.items()}
+    else:
+        compute_device = None
+
     def model(x, t, y=None, y2=None, w=None, **kw):
-        return diffma_forward_ref(sd, x.double(), t, y.double(), y2.double(), w.double(), patch_size=patch, depth=depth,
-                                  dtype=torch.float64).float()
+        mv = (lambda v: v.to(compute_device)) if compute_device is not None else (lambda v: v)
+        out = diffma_forward_ref(sd, mv(x.double()), mv(t), mv(y.double()), mv(y2.double()), mv(w.double()), patch_size=patch, depth=depth,
+                                 dtype=torch.float64).float()
+        return out.to(x.device)
     return model
 
 
@@ -133,7 +143,7 @@ def test_sample_main_matches_oracle_driven_loop(gpu, monkeypatch, tmp_path, ddim
     gen = torch.Generator(device=gpu).manual_seed(seed)
     mk = lambda *s: torch.randn(*s, generator=gen, device=gpu)
     d = create_diffusion(f"ddim{steps}" if ddim else str(steps))
-    model = _oracle_denoiser(sd, patch, depth)
+    model = _oracle_denoiser(sd, patch, depth, compute_device=gpu)       # the loop below stays on the host
     tape.rewind()
     for b in range(nb):
         z = mk(n, 4, 28, 28)

@@ -373,6 +373,21 @@ def test_token_merge_exact(gpu):
     assert torch.equal(out2, (slabs[0] + slabs[1]) + slabs[2])
 
 
+def _oracle_device(gpu, elems):
+    """Where the oracle's torch code (fp64 autograd through oracle/mamba_ref.py) runs for one test case: the host for small cases,
+    the DEVICE for the full-width ones -- the same oracle functions on ATen's fp64 kernels instead of 30-60 s of host time per case
+    (the GPU suite has a 1 200 s limit; DIFFMA_TEST_ORACLE_ON_HOST=1 puts everything back on the host)."""
+    if os.environ.get("DIFFMA_TEST_ORACLE_ON_HOST") == "1" or elems < (1 << 18):
+        return torch.device("cpu")
+    return gpu
+
+
+def _grads_to_cpu(*leaves):
+    """Leaves of an oracle autograd run -> stand-ins that carry `.grad` on the host (the checks compare on the host)."""
+    import types
+    return [None if t is None else types.SimpleNamespace(grad=None if t.grad is None else t.grad.detach().cpu()) for t in leaves]
+
+
 def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bsz=None, a_shared=False, dout_per_seq=False,
                    variant="sequential"):
     """a_shared: A[d, :] is one value per channel and the kernels run their DM_FLAG_A_SHARED form (one exp per channel-step, the
@@ -411,32 +426,37 @@ def _scan_bwd_case(gpu, dtype, S, L, Dm, N, seed, with_z=True, indexed=False, Bs
     torch.cuda.synchronize()
     du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
 
-    # fp64 autograd of the oracle on the same (rounded) inputs
-    leaf = lambda t: t.float().double().clone().requires_grad_(True)
+    # fp64 autograd of the oracle on the same (rounded) inputs; the big cases run the oracle's torch code on the device (_oracle_device)
+    odev = _oracle_device(gpu, S * L * Dm)
+    leaf = lambda t: t.float().double().to(odev).clone().requires_grad_(True)
     u, dl, A, Bm, Cm, Dp, bias = leaf(host["u"]), leaf(host["delta"]), leaf(host["A"]), leaf(host["B"]), leaf(host["C"]), leaf(host["D"]), leaf(host["bias"])
     cm = lambda t: t.permute(0, 2, 1)
+    dout_o = dout.float().double().to(odev)
     if indexed:
         z = leaf(zsrc)
         ndir = S // Bsz
-        zs = torch.cat([z[:, zperm[k].long(), :] for k in range(ndir)], 0)        # [S, L, Dm] gathered
+        zp_o, op_o = zperm.long().to(odev), operm.long().to(odev)
+        zs = torch.cat([z[:, zp_o[k], :] for k in range(ndir)], 0)        # [S, L, Dm] gathered
         y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=cm(zs), delta_bias=bias, delta_softplus=True))
         # scatter: merged[b, operm[k][l]] += y[k*Bsz+b, l]
         if dout_per_seq:                   # direction k's step l lands in row operm[k][l] of ITS OWN token-order slab
             loss = 0
             for k in range(ndir):
-                slab = torch.zeros(Bsz, L, Dm, dtype=torch.float64).index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
-                loss = loss + (slab * dout[k * Bsz:(k + 1) * Bsz].float().double()).sum()
+                slab = torch.zeros(Bsz, L, Dm, dtype=torch.float64, device=odev).index_add(1, op_o[k], y[k * Bsz:(k + 1) * Bsz])
+                loss = loss + (slab * dout_o[k * Bsz:(k + 1) * Bsz]).sum()
         else:
-            merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+            merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64, device=odev)
             for k in range(ndir):
-                merged = merged.index_add(1, operm[k].long(), y[k * Bsz:(k + 1) * Bsz])
-            loss = (merged * dout.float().double()).sum()
+                merged = merged.index_add(1, op_o[k], y[k * Bsz:(k + 1) * Bsz])
+            loss = (merged * dout_o).sum()
     else:
         z = leaf(host["z"]) if with_z else None
         y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=None if z is None else cm(z), delta_bias=bias,
                                   delta_softplus=True))
-        loss = (y * dout.float().double()).sum()
+        loss = (y * dout_o).sum()
     loss.backward()
+    u, dl, A, Bm, Cm, Dp, bias, z = _grads_to_cpu(u, dl, A, Bm, Cm, Dp, bias, z)
+    y = y.detach().cpu()
     rtol, atol = {torch.float32: (2e-4, 2e-5), torch.bfloat16: (4e-2, 6e-2), torch.float16: (5e-3, 8e-3)}[dtype]
     # the forward of the same launch (gated output) against the oracle too
     rf, af = TOL[dtype]
@@ -902,16 +922,19 @@ def _hoisted_scan_case(gpu, dtype, Bsz, L, Dm, ndir, variant, seed):
     du, ddelta, dz, dB, dC, dA, dD, dbias = [None if t is None else t.float().cpu().double() for t in res]
     assert dz is None
 
-    leaf = lambda t: t.float().double().clone().requires_grad_(True)
+    odev = _oracle_device(gpu, S * L * Dm)
+    leaf = lambda t: t.float().double().to(odev).clone().requires_grad_(True)
     u, dl, A, Bm, Cm, Dp = leaf(host["u"]), leaf(act), leaf(host["A"]), leaf(host["B"]), leaf(host["C"]), leaf(host["D"])
     cm = lambda t: t.permute(0, 2, 1)
     y = cm(selective_scan_ref(cm(u), cm(dl), A, cm(Bm), cm(Cm), Dp, z=None, delta_bias=None, delta_softplus=False))
-    merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64)
+    merged = torch.zeros(Bsz, L, Dm, dtype=torch.float64, device=odev)
     for k in range(ndir):
-        merged = merged.index_add(1, perm[k].long(), y[k * Bsz:(k + 1) * Bsz])
-    (merged * dout.float().double()).sum().backward()
+        merged = merged.index_add(1, perm[k].long().to(odev), y[k * Bsz:(k + 1) * Bsz])
+    (merged * dout.float().double().to(odev)).sum().backward()
+    dl_val = dl.detach().cpu()
+    u, dl, A, Bm, Cm, Dp = _grads_to_cpu(u, dl, A, Bm, Cm, Dp)
     rf, af = TOL[dtype]
-    yref = y.detach()
+    yref = y.detach().cpu()
     for k in range(ndir):
         got = out.float().cpu().double()[k * Bsz:(k + 1) * Bsz][:, perm[k].long()]
         torch.testing.assert_close(got, yref[k * Bsz:(k + 1) * Bsz], rtol=rf, atol=af * max(1.0, yref.abs().max().item()))
@@ -921,7 +944,7 @@ def _hoisted_scan_case(gpu, dtype, Bsz, L, Dm, ndir, variant, seed):
         sc = max(1.0, ref.abs().max().item())
         torch.testing.assert_close(got, ref, rtol=rtol, atol=atol * sc * sum_scale, msg=lambda m: f"{name}: {m}")
 
-    draw = dl.grad * (1.0 - torch.exp(-dl.detach()))                                       # chain through softplus: sigmoid(raw)
+    draw = dl.grad * (1.0 - torch.exp(-dl_val))                                            # chain through softplus: sigmoid(raw)
     wide = max(1.0, (Dm / 128.0) ** 0.5) if dtype != torch.float32 else 1.0
     chk(du, u.grad, "du")
     chk(ddelta, draw, "ddelta (raw)")

@@ -866,9 +866,13 @@ def test_baseline_config_models_match_oracle_at_full_size(gpu, name, kw):
     x, y, y2 = torch.randn(1, 4, 28, 28, generator=g), torch.randn(1, 512, generator=g), torch.randn(1, L, 512, generator=g)
     w = torch.sigmoid(torch.randn(1, L, 1, generator=g))
     t = torch.tensor([437])
-    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
-    ref, blocks = diffma_forward_ref(sd, x, t, y, y2, w, patch_size=patch, depth=depth, dtype=torch.float32, return_blocks=True,
-                                     use_mamba2=kw.get("use_mamba2", False))
+    # the oracle's torch code runs on the device for the full-size models (ATen fp32 kernels; 106 s of host time for XXL/2 otherwise)
+    odev = torch.device("cpu") if os.environ.get("DIFFMA_TEST_ORACLE_ON_HOST") == "1" else gpu
+    sd = {k: v.detach().clone().to(odev) for k, v in net.state_dict().items()}
+    ref, blocks = diffma_forward_ref(sd, x.to(odev), t.to(odev), y.to(odev), y2.to(odev), w.to(odev), patch_size=patch, depth=depth,
+                                     dtype=torch.float32, return_blocks=True, use_mamba2=kw.get("use_mamba2", False))
+    ref, blocks = ref.cpu(), [b.cpu() for b in blocks]
+    del sd
     net = net.to(gpu)
     acts = {}
     hooks = [b.register_forward_hook(lambda m, i, o, k=k: acts.__setitem__(k, o.detach().cpu())) for k, b in enumerate(net.blocks)]
@@ -1155,6 +1159,11 @@ def test_paired_mixers_equal_two_unpaired_mixers_and_halve_the_launches(gpu, mon
     assert n1 < n0 and (n0 - n1) >= 10, (n0, n1)
 
 
+# bounds of the bench-dispatch end-to-end test = 2x the worst case measured on MI355X (profiles/r06_e2e_bench_dispatch_worst.json: output rel-L2
+# 3.9e-3; worst parameter gradient 2.04e-2 -- the bias of the fusion MLP's last layer of block 0, a sum over 34 496 bf16 rows)
+E2E_OUT_TOL, E2E_GRAD_TOL = 8e-3, 4e-2
+
+
 def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
     """The composition the bench times, end to end, with NO thresholds patched: a depth-2 DiffMa at the L/2
     width (hidden 512 -> d_inner 1024, dt_rank 32 = hidden / 16, 28 x 28 latents -> L = 196), batch 176 (3 x 176 = 528 sequences >= 512), bf16
@@ -1162,8 +1171,8 @@ def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
     form, the sequential scans K1 / K2, K8 / K8b, the split-K weight gradients and the large-batch projections; the launch log
     below asserts that they are what ran.  Reference arithmetic: fp64 autograd through oracle.model_ref (the fp64 oracle runs ON
     THE DEVICE here, 16 samples at a time -- its sequential scan keeps ~0.6 GB per sample for autograd -- and its parameter
-    gradients are summed over the chunks; it is the checker, not the path).  Bounds: output rel-L2 <= 2e-2, every parameter gradient
-    rel-L2 <= 6e-2 (bf16 activations, fp32 master weights)."""
+    gradients are summed over the chunks; it is the checker, not the path).  Bounds: output rel-L2 <= 8e-3, every parameter gradient
+    rel-L2 <= 4e-2 (bf16 activations, fp32 master weights): twice the measured worst case, which the assert message reports."""
     from diffma_amd import _lib, hip_ops
     from diffma_amd import selective_scan_interface as ssi
     from diffma_amd.diffusion import create_diffusion
@@ -1245,13 +1254,20 @@ def test_bench_dispatch_end_to_end_matches_oracle(gpu, monkeypatch):
         ref_loss += float(part.detach())
     ref_out = torch.cat(ref_out).detach()
     assert float(ref_out.abs().mean()) > 1e-3
-    assert rel_l2(out.detach().float().cpu(), ref_out.cpu()) <= 2e-2, rel_l2(out.detach().float().cpu(), ref_out.cpu())
+    assert rel_l2(out.detach().float().cpu(), ref_out.cpu()) <= E2E_OUT_TOL, rel_l2(out.detach().float().cpu(), ref_out.cpu())
     assert abs(float(loss.detach()) - ref_loss) <= 1e-2 * abs(ref_loss), (float(loss.detach()), ref_loss)
     worst = {}
     for k, gr in got.items():
         worst[k] = rel_l2(gr.cpu(), sd64[k].grad.cpu())
-    bad = {k: v for k, v in worst.items() if not v <= 6e-2}
-    assert not bad, bad
+    wk = max(worst, key=worst.get)
+    rep = os.environ.get("DIFFMA_TEST_REPORT_DIR")
+    if rep:                                                    # measured worst cases of this run (tools/r06_gpu_checks.sh keeps them under profiles/)
+        import json
+        with open(os.path.join(rep, "e2e_bench_dispatch_worst.json"), "w") as f:
+            json.dump({"out_rel_l2": rel_l2(out.detach().float().cpu(), ref_out.cpu()), "worst_grad": [wk, worst[wk]],
+                       "grads_rel_l2": dict(sorted(worst.items(), key=lambda kv: -kv[1])[:12])}, f, indent=1)
+    bad = {k: v for k, v in worst.items() if not v <= E2E_GRAD_TOL}
+    assert not bad, f"{len(bad)} gradients above {E2E_GRAD_TOL}: {bad}; worst of all {wk} = {worst[wk]:.3e}"
     assert len(got) == sum(1 for k in sd64 if k != "pos_embed")
 
 
