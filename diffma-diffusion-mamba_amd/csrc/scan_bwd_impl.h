@@ -367,7 +367,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
         for (int i = 0; i < SUB; ++i) {
             const int l = (lb + i < L) ? lb + i : L - 1;
-            r[i] = IDX ? tab[l] : l;
+            r[i] = IDX ? tab[(uint32_t)l] : l;                     // (unsigned: no sign extension of the index on the scalar unit)
         }
         return r;
     };
