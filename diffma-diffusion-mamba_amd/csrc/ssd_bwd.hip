@@ -85,51 +85,6 @@ __device__ __forceinline__ void acc_to_frags(const f32x16& d, ssd_u32x4 (&f)[2])
                             O::pack(d[8 * ks + 6], d[8 * ks + 7])};
 }
 
-// The same two K-step fragments of a 16-bit B-operand whose contraction index runs over SEQUENCE POSITIONS, read straight from
-// the row-major LDS arrays with the transposing LDS read of gfx950 (`ds_read_b64_tr_b16`: inside a 16-lane group lane fi hands in
-// the address of 4 consecutive 16-bit elements -- row fi >> 2, columns 4 (fi & 3) .. of a [4 rows][16 columns] block -- and gets
-// back column fi of that block, rows 0 .. 3).  Lane (n = l & 31, kh = l >> 5) needs channel `col0 + n` at the positions that the
-// accumulator-ordered A-fragment (acc_to_frags) carries in the same slots: slot e of K-step ks = row0 + 16 ks + 8 (e >> 2) + 4 kh + (e & 3).
-// Rounds 2-5 produced these fragments with 0/1 selector MFMAs (5 of the 16 MFMAs per tile pair, plus 24 conversions and the
-// accumulator read-out); the values are the same bits.
-typedef short ssd_v4s __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) ssd_v4s* ssd_tr_ptr;
-typedef uint32_t ssd_u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ssd_u32x2 tr_read4(const uint8_t* p) {
-    return __builtin_bit_cast(ssd_u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((ssd_tr_ptr)p));
-}
-// X / gY arrays: [197][64], 16-byte chunks XOR-swizzled by (row & 7); col0 = 0 or 32
-__device__ __forceinline__ void tr_frags_rows(const uint8_t* base, int row0, int col0, int lane, ssd_u32x4 (&f)[2]) {
-    const int fi = lane & 15, gq = lane >> 4, kh = lane >> 5;
-    const int ch8 = (col0 >> 3) + 2 * (gq & 1) + ((fi & 3) >> 1), half = fi & 1;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        ssd_u32x2 v[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int row = row0 + 16 * ks + 8 * hh + 4 * kh + (fi >> 2);
-            const int rc = row < SB_MAXL ? row : SB_MAXL;
-            v[hh] = tr_read4(base + rc * 128 + ((ch8 ^ (rc & 7)) << 4) + half * 8);
-        }
-        f[ks] = (ssd_u32x4){v[0].x, v[0].y, v[1].x, v[1].y};
-    }
-}
-// B / C arrays: [197][16]; the 32-wide operand has its columns 16 .. 31 empty: those lanes read the zero row
-__device__ __forceinline__ void tr_frags_bc(const uint8_t* base, int row0, int lane, ssd_u32x4 (&f)[2]) {
-    const int fi = lane & 15, gq = lane >> 4, kh = lane >> 5;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        ssd_u32x2 v[2];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int row = row0 + 16 * ks + 8 * hh + 4 * kh + (fi >> 2);
-            const int rc = (row < SB_MAXL && !(gq & 1)) ? row : SB_MAXL;
-            v[hh] = tr_read4(base + rc * 32 + (fi & 3) * 8);
-        }
-        f[ks] = (ssd_u32x4){v[0].x, v[0].y, v[1].x, v[1].y};
-    }
-}
-
 // Inclusive prefix sum over the workgroup's 256 threads (one value each): six shuffle steps inside each wave, one barrier to pass
 // the wave totals on.  Every thread of the workgroup must call it.
 __device__ __forceinline__ float block_prefix_sum(float v, int lane, int w, float* wtot) {
@@ -323,6 +278,10 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     const int row8 = lane >> 3, c8 = lane & 7;                                    // epilogue role: row of an 8-row slab, 16-byte chunk
     float* const stage = reinterpret_cast<float*>(lds + SB_STAGE) + w * 8 * SB_STG;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // selectors: a [positions x 64 channels] row-major fragment set times these = the 32-channel half nt in accumulator layout
+    // (K-step j of the half: channel 32 nt + q sits in slot q - 16 j - 8 kh); states likewise (16 of them, columns 16-31 empty)
+    const ssd_u32x4 selx[2] = {one_hot<T>(q - 8 * kh), one_hot<T>(q - 16 - 8 * kh)};
+    const ssd_u32x4 sel16 = one_hot<T>(q < 16 ? q - 8 * kh : -1);
     // role of the wave: waves land on SIMD (w & 3); the T waves carry the heavier epilogue, so odd heads swap the roles and the two
     // workgroups a CU holds put one T and one N wave on every SIMD
     const int wr = (w + 2 * (int)(blockIdx.x & 1)) & 3;
@@ -368,9 +327,9 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
                 for (int ks = 0; ks < 4; ++ks) rr = O::mfma(xA[ks], gB[ks], rr);   // R = gY . X
                 // X and B of the key tile with the keys in the K slots (accumulator order): selector products
                 ssd_u32x4 xf0[2], xf1[2], bf[2];
-                tr_frags_rows(lds + SB_XS, SB_TILE * it, 0, lane, xf0);
-                tr_frags_rows(lds + SB_XS, SB_TILE * it, 32, lane, xf1);
-                tr_frags_bc(lds + SB_BS, SB_TILE * it, lane, bf);
+                acc_to_frags<O>(O::mfma(xA[1], selx[1], O::mfma(xA[0], selx[0], zero16)), xf0);
+                acc_to_frags<O>(O::mfma(xA[3], selx[1], O::mfma(xA[2], selx[0], zero16)), xf1);
+                acc_to_frags<O>(O::mfma(bA, sel16, zero16), bf);
                 const int kb = SB_TILE * it + 4 * kh;
                 float md[16];                                                     // M[query][key] * dt_key
                 if (it < lt) {
@@ -481,9 +440,9 @@ __global__ __launch_bounds__(SB_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) rr = O::mfma(gA[ks], xB[ks], rr);
                 ssd_u32x4 gf0[2], gf1[2], cf[2];                                   // gY and C of the query tile with the queries in the K slots
-                tr_frags_rows(lds + SB_GS, SB_TILE * lt, 0, lane, gf0);
-                tr_frags_rows(lds + SB_GS, SB_TILE * lt, 32, lane, gf1);
-                tr_frags_bc(lds + SB_CS, SB_TILE * lt, lane, cf);
+                acc_to_frags<O>(O::mfma(gA[1], selx[1], O::mfma(gA[0], selx[0], zero16)), gf0);
+                acc_to_frags<O>(O::mfma(gA[3], selx[1], O::mfma(gA[2], selx[0], zero16)), gf1);
+                acc_to_frags<O>(O::mfma(cA, sel16, zero16), cf);
                 const int qb = SB_TILE * lt + 4 * kh;
                 float mf[16];                                                     // M[query][key] (without dt)
                 if (lt > it) {
