@@ -129,17 +129,23 @@ __device__ __forceinline__ int opaque_i(int x) {
     return x;
 }
 
-// LDS row pointer whose element offset is opaque to the optimiser (the row is RE-READ instead of being kept in
-// VGPRs across the chunk) but still known to be a multiple of 4 floats, so the reads stay ds_read_b128
-__device__ __forceinline__ const float* lds_row(const float* base, int elem_off) {
-    return reinterpret_cast<const float*>(__builtin_assume_aligned(base + opaque_i(elem_off), 16));
+// LDS rows of the staged B / C values are RE-READ at every use instead of being kept in VGPRs across the chunk: the chunk's base
+// address (an LDS pointer in one VGPR) is made opaque to the optimiser once per pass over a sub-chunk (the recompute and the sweep must not share row values: 24
+// VGPRs held across both), and the row's place inside the chunk -- a
+// compile-time constant in the unrolled loop -- rides in the ds_read's immediate offset: no address instruction per row.  (Rounds 3-5
+// made the element OFFSET opaque instead: an s_or, a v_mov and a v_lshl_add per row read, 84 instructions per 8-step chunk.)
+typedef __attribute__((address_space(3))) const float* lds_cfptr;
+typedef __attribute__((address_space(3))) const f32x4* lds_cf4ptr;
+__device__ __forceinline__ lds_cfptr lds_opaque(lds_cfptr chunk_base) {      // one register copy; taken once per pass (recompute / sweep) of a state group
+    asm volatile("" : "+v"(chunk_base));
+    return chunk_base;
 }
 template <int NS>
-__device__ __forceinline__ void lds_ld_vec(float (&v)[NS], const float* row) {
+__device__ __forceinline__ void lds_ld_vec(float (&v)[NS], lds_cfptr row) {
     if constexpr (NS % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < NS / 4; ++k) {
-            const f32x4 t = reinterpret_cast<const f32x4*>(row)[k];
+            const f32x4 t = ((lds_cf4ptr)row)[k];
             v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
         }
     } else {
@@ -390,14 +396,24 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
         orow_is = load_rows(oidx, ci - 1);
         if (HAS_Z) zrow_is = load_rows(zidx, ci - 1);
     };
-    uint32_t ck_end[H0W];                                        // state entering the sub-chunk processed BEFORE this one = this one's end state
+    // state entering the sub-chunk processed BEFORE this one = this one's end state.  HALVES keeps it UNPACKED (the sub-chunk's own
+    // entering state hs[0] is handed on as it is: 16 shift / mask instructions per sub-chunk less for 8 more registers); the
+    // whole-channel forms keep the raw words
+    uint32_t ck_end[H0W];
     load_state(nchunk * NSC, ck_end);
+    f32x2 hend[HALVES ? NH : 1][NPH];
+    if constexpr (HALVES) {
+#pragma unroll
+        for (int hf = 0; hf < NH; ++hf) unpack_state(hend[hf], ck_end, hf);
+    }
     i32x4_t zrow_nx = zrow_is;                                   // z rows of the sub-chunk in flight (its dz stores need them)
     issue_sub(nchunk * NSC - 1);
 
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int l0 = ch * CK;
+        // this chunk's staged rows (the lane's state slice of every row): one LDS address for the whole chunk
+        const lds_cfptr bc_chunk = (lds_cfptr)(&bc_lds[0][0][0]) + (buf * CK * 2 * N + q * NS);
         uint32_t bc_next[BC_PER_THREAD];
         fetch_bc(ch > 0 ? ch - 1 : 0, bc_next);         // lands while this chunk computes (unconditional: a branch would pin the wait to the load)
         // Sub-chunks of SUB steps, last one first; each starts from its own checkpoint and its SUB states live in
@@ -435,9 +451,10 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int hf = 0; hf < NH; ++hf) {
             // one forward step of the group: h <- a*h + B*dl*u   (a kept in `keep` when the sweep will reuse it)
+            const lds_cfptr bc_rec = lds_opaque(bc_chunk);
             auto fwd_step = [&](f32x2(&h)[NPH], int i, f32x2(&keep)[NPH]) {
                 float Bv[2 * NPH];
-                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + sc * SUB + i) * 2 * N + q * NS + hf * 2 * NPH);   // re-read, do not keep rows in VGPRs
+                const lds_cfptr brow = bc_rec + ((sc * SUB + i) * 2 * N + hf * 2 * NPH);          // re-read, do not keep rows in VGPRs
                 if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) Bv[k] = opaque(1.0f); } else
                 lds_ld_vec<2 * NPH>(Bv, brow);
                 const float dlo = CACHE_A ? dl[i] : opaque(dl[i]);
@@ -472,8 +489,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 if (i < SUB - 1) fwd_step(h, i, aa[CACHE_A ? i : 0]);
             }
             // the state after the sub-chunk's last step is the checkpoint of the sub-chunk processed before: one recomputed step less
-            unpack_state(h, ck_end, hf);
+            if constexpr (HALVES) {
+#pragma unroll
+                for (int k = 0; k < NPH; ++k) { h[k] = hend[hf][k]; hend[hf][k] = hs[0][k]; }
+            } else {
+                unpack_state(h, ck_end, hf);
+            }
             // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
+            const lds_cfptr bc_swp = lds_opaque(bc_chunk);
 #pragma unroll
             for (int i = SUB - 1; i >= 0; --i) {
                 const int j = sc * SUB + i;
@@ -481,7 +504,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const bool valid = lraw < L;                    // wave-uniform
                 const int l = valid ? lraw : L - 1;
                 float Bv[2 * NPH], Cv[2 * NPH];
-                const float* brow = lds_row(&bc_lds[0][0][0], (buf * CK + j) * 2 * N + q * NS + hf * 2 * NPH);
+                const lds_cfptr brow = bc_swp + (j * 2 * N + hf * 2 * NPH);
                 if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
                 lds_ld_vec<2 * NPH>(Bv, brow);
                 lds_ld_vec<2 * NPH>(Cv, brow + N); }
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             }
             }   // hf
 #pragma unroll
-            for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];
+            for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];      // (dead in the HALVES form: removed by the compiler)
         }
         if (!(DM_K2_EXP & 2)) __syncthreads();
         if (!(DM_K2_EXP & 35)) flush_dbc(ch);

@@ -1695,6 +1695,41 @@ def test_fused_adamw_ema_matches_torch(gpu, wd):
     assert len(sd["state"]) == len(pb) and float(sd["state"][0]["step"]) == 3.0
 
 
+# ---- K15 against numbers the REFERENCE produced (G3: the reference's own training_losses / q_sample on a fixed fake denoiser) ----
+@pytest.mark.parametrize("tag,spec", [("full", ""), ("s250", "250")])
+def test_fused_training_losses_match_reference_golden(gpu, tag, spec):
+    """dm_q_sample + dm_training_loss (csrc/diffusion_loss.hip) through GaussianDiffusion.training_losses on the device against
+    tests/golden/g3_diffusion_steps.npz -- x_t, mse, vb and loss as the reference's gaussian_diffusion.py:715-789 computed them
+    (tools/gen_golden.py ran the reference with the same deterministic stand-in denoiser): the fused path held to reference-held
+    values, not to this repository's generic path.  fp32: rtol 2e-5 like the CPU test of the generic path."""
+    import numpy as np
+    from diffma_amd.diffusion import create_diffusion
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g3_diffusion_steps.npz"))
+    x0, noise = (torch.from_numpy(g[k]).to(gpu) for k in ("x0", "noise"))
+    t = torch.from_numpy(g[f"{tag}.t"]).to(gpu)
+    d = create_diffusion(spec)
+    seen = {}
+
+    def fake_model(x, tt, **kw):                       # tools/gen_golden.py fake_model
+        seen["x_t"] = x
+        return torch.cat([torch.sin(x) + tt.view(-1, 1, 1, 1).float() / 1000.0, torch.cos(x)], dim=1)
+
+    from diffma_amd import _lib
+    log = []
+    real_call = _lib.call
+    _lib.call = lambda name, a, st: (log.append(name), real_call(name, a, st))[1]
+    try:
+        assert d.fused_loss
+        terms = d.training_losses(fake_model, x0, t, noise=noise)
+    finally:
+        _lib.call = real_call
+    assert "dm_q_sample" in log and "dm_training_loss" in log, log     # the fused kernels are what ran
+    np.testing.assert_allclose(seen["x_t"].cpu().numpy(), g[f"{tag}.q_sample"], rtol=2e-5, atol=2e-6)
+    for k in ("mse", "vb", "loss"):
+        np.testing.assert_allclose(terms[k].detach().cpu().numpy(), g[f"{tag}.loss.{k}"], rtol=2e-5, atol=2e-6, err_msg=f"{tag}.loss.{k}")
+
+
 # ---- K15 dm_q_sample / dm_training_loss: the diffusion wrapper around the denoiser call of a training step ----
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("spec", ["", "250"])
