@@ -41,7 +41,8 @@
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
 #endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
-                               // 32 dB/dC products and conversions kept but no MFMA / LDS write / flush, 64 no u / delta / dy loads
+                               // 32 dB/dC products and conversions kept but no MFMA / LDS write / flush, 64 no u / delta / dy loads,
+                               // 128 the two MFMAs of a state group replaced by four XORs (LDS write and flush kept): the MFMAs' own price
 
 namespace dm {
 
@@ -592,7 +593,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     // this group's 16 values (dB and dC of its 8 states) = ONE pair of MFMAs; LDS group hf (flush_dbc maps the columns)
                     const u32x4_t lo = {pk_all[0], pk_all[1], pk_all[2], pk_all[3]};
                     const u32x4_t hi = {pk_all[4], pk_all[5], pk_all[6], pk_all[7]};
-                    const f32x4 dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
+                    f32x4 dsum;
+                    if constexpr (DM_K2_EXP & 128) dsum = (f32x4){__uint_as_float(lo[0] ^ hi[0]), __uint_as_float(lo[1] ^ hi[1]), __uint_as_float(lo[2] ^ hi[2]), __uint_as_float(lo[3] ^ hi[3])};
+                    else dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
                     *reinterpret_cast<f32x4*>(&red_lds[wave][j][hf * RED_HALF + red_slot]) = dsum;
                 } else if constexpr (MFMA_RED) {
 #pragma unroll
