@@ -38,6 +38,12 @@
 #ifndef DM_K2_HALVES
 #define DM_K2_HALVES 1         // developer A/B: 0 = the whole channel's 16 states in one pass (rounds 3-5)
 #endif
+#ifndef DM_K2_DEFER_WRITE
+#define DM_K2_DEFER_WRITE 0    // developer A/B: 0 = the lane-group totals are written to LDS right behind their MFMAs
+#endif
+#ifndef DM_K2_LDS_AHEAD
+#define DM_K2_LDS_AHEAD 1      // developer A/B: 0 = a step's B / C rows are read at its top, 1 = read ahead in the sweep only, 2 = in the recompute too
+#endif
 #ifndef DM_K2_EXP
 #define DM_K2_EXP 0            // developer timing experiments (bit mask; results are WRONG when non-zero): 1 no dB/dC reduction,
 #endif                         // 2 no barriers / flush, 4 no checkpoint loads, 8 no du / ddelta stores, 16 no LDS B/C re-reads,
@@ -167,6 +173,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     constexpr bool HALVES = (DM_K2_HALVES != 0) && MFMA_RED && SPLIT == 1 && N == 16;
     constexpr int NH = HALVES ? 2 : 1, NPH = NPL / NH;
     constexpr bool CACHE_A = HALVES && !ASH;
+    // (the variants with z carry zz[] / sz / ypre as well: the 16 read-ahead registers spill there -- they keep the read at the step's top)
+    constexpr bool LDS_AHEAD = HALVES && !HAS_Z && (DM_K2_LDS_AHEAD != 0), LDS_AHEAD_REC = LDS_AHEAD && (DM_K2_LDS_AHEAD >= 2);
+    constexpr bool DEFER_WRITE = LDS_AHEAD && (DM_K2_DEFER_WRITE != 0);
     static_assert(N % SPLIT == 0 && NS % 2 == 0, "d_state/SPLIT must be even");
     static_assert(CK % SUB == 0, "chunk must be a whole number of sub-chunks");
     // lane-group totals of the dB/dC products, one R-float slot per lane; every 16-lane row is shifted by 2R floats so
@@ -413,6 +422,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
     int buf = 0;
     for (int ch = nchunk - 1; ch >= 0; --ch) {
         const int l0 = ch * CK;
+        f32x4 pend = {0.f, 0.f, 0.f, 0.f};                 // DM_K2_DEFER_WRITE: lane-group totals on their way to LDS
+        int pend_off = 0;
+        bool pend_have = false;
         // this chunk's staged rows (the lane's state slice of every row): one LDS address for the whole chunk
         const lds_cfptr bc_chunk = (lds_cfptr)(&bc_lds[0][0][0]) + (buf * CK * 2 * N + q * NS);
         uint32_t bc_next[BC_PER_THREAD];
@@ -453,10 +465,17 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
             for (int hf = 0; hf < NH; ++hf) {
             // one forward step of the group: h <- a*h + B*dl*u   (a kept in `keep` when the sweep will reuse it)
             const lds_cfptr bc_rec = lds_opaque(bc_chunk);
+            float Brn[2 * NPH];                                          // LDS_AHEAD: the B row of the NEXT recomputed step
+            if constexpr (LDS_AHEAD_REC) lds_ld_vec<2 * NPH>(Brn, bc_rec + ((sc * SUB) * 2 * N + hf * 2 * NPH));
             auto fwd_step = [&](f32x2(&h)[NPH], int i, f32x2(&keep)[NPH]) {
                 float Bv[2 * NPH];
                 const lds_cfptr brow = bc_rec + ((sc * SUB + i) * 2 * N + hf * 2 * NPH);          // re-read, do not keep rows in VGPRs
-                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) Bv[k] = opaque(1.0f); } else
+                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) Bv[k] = opaque(1.0f); } else if constexpr (LDS_AHEAD_REC) {
+#pragma unroll
+                    for (int k = 0; k < 2 * NPH; ++k) Bv[k] = Brn[k];
+                    if (i + 1 < SUB - 1) lds_ld_vec<2 * NPH>(Brn, brow + 2 * N);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else
                 lds_ld_vec<2 * NPH>(Bv, brow);
                 const float dlo = CACHE_A ? dl[i] : opaque(dl[i]);
                 const float du = dlo * uu[i];
@@ -497,7 +516,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 unpack_state(h, ck_end, hf);
             }
             // ---- reverse sweep over the sub-chunk (h = state AFTER step j at the top of iteration j) -------
+            // LDS_AHEAD: the B / C rows of step i - 1 are requested BEFORE step i is computed (a scheduling fence keeps the reads there),
+            // so that no step starts by waiting for its own rows -- with two groups per step the sweep has twice as many read groups as
+            // the whole-channel form, and SQ_WAIT_ANY had gone from 14 % to 23 % of the wave-cycles (profiles/r06_k2_decay_reuse.txt)
             const lds_cfptr bc_swp = lds_opaque(bc_chunk);
+            float Bn[2 * NPH], Cn[2 * NPH];
+            if constexpr (LDS_AHEAD) {
+                const lds_cfptr r0 = bc_swp + ((sc * SUB + SUB - 1) * 2 * N + hf * 2 * NPH);
+                lds_ld_vec<2 * NPH>(Bn, r0);
+                lds_ld_vec<2 * NPH>(Cn, r0 + N);
+            }
 #pragma unroll
             for (int i = SUB - 1; i >= 0; --i) {
                 const int j = sc * SUB + i;
@@ -506,7 +534,15 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                 const int l = valid ? lraw : L - 1;
                 float Bv[2 * NPH], Cv[2 * NPH];
                 const lds_cfptr brow = bc_swp + (j * 2 * N + hf * 2 * NPH);
-                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else {
+                if (DM_K2_EXP & 16) { for (int k = 0; k < 2 * NPH; ++k) { Bv[k] = opaque(1.0f); Cv[k] = opaque(0.5f); } } else if constexpr (LDS_AHEAD) {
+#pragma unroll
+                    for (int k = 0; k < 2 * NPH; ++k) { Bv[k] = Bn[k]; Cv[k] = Cn[k]; }
+                    if (i > 0) {
+                        lds_ld_vec<2 * NPH>(Bn, brow - 2 * N);
+                        lds_ld_vec<2 * NPH>(Cn, brow - 2 * N + N);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
                 lds_ld_vec<2 * NPH>(Bv, brow);
                 lds_ld_vec<2 * NPH>(Cv, brow + N); }
                 const float g = gg[i];
@@ -596,7 +632,16 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
                     f32x4 dsum;
                     if constexpr (DM_K2_EXP & 128) dsum = (f32x4){__uint_as_float(lo[0] ^ hi[0]), __uint_as_float(lo[1] ^ hi[1]), __uint_as_float(lo[2] ^ hi[2]), __uint_as_float(lo[3] ^ hi[3])};
                     else dsum = mfma_group_sum16(sel_lo, sel_hi, lo, hi);
-                    *reinterpret_cast<f32x4*>(&red_lds[wave][j][hf * RED_HALF + red_slot]) = dsum;
+                    if constexpr (DEFER_WRITE) {
+                        // the totals leave for LDS one group-step LATER: written right behind its MFMAs the ds_write parks the wave until the
+                        // matrix pipe has delivered (the read-ahead fence keeps the MFMAs at the end of the step)
+                        if (pend_have) *reinterpret_cast<f32x4*>(&red_lds[wave][0][0] + pend_off) = pend;
+                        pend = dsum;
+                        pend_off = j * RED_ROW + hf * RED_HALF + red_slot;
+                        pend_have = true;
+                    } else {
+                        *reinterpret_cast<f32x4*>(&red_lds[wave][j][hf * RED_HALF + red_slot]) = dsum;
+                    }
                 } else if constexpr (MFMA_RED) {
 #pragma unroll
                     for (int g16 = 0; g16 < M / 16; ++g16) {   // 16 values (8 pairs) per pair of MFMAs; register r of group g16 = value 16*g16 + 4*(lane>>4) + r
@@ -616,6 +661,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int k = 0; k < H0W; ++k) ck_end[k] = ck_cur[k];      // (dead in the HALVES form: removed by the compiler)
         }
+        if (pend_have) *reinterpret_cast<f32x4*>(&red_lds[wave][0][0] + pend_off) = pend;
         if (!(DM_K2_EXP & 2)) __syncthreads();
         if (!(DM_K2_EXP & 35)) flush_dbc(ch);
         if (ch > 0) stash_bc(buf ^ 1, bc_next);
