@@ -360,6 +360,15 @@ def test_bench_under_torchrun_over_rccl_one_rank(gpu, compression, tmp_path):
     assert d["value"] > 0 and d["ms_per_step"] > 0 and 0 < d["roofline"]["frac"] < 1
     assert d["roofline"]["kernel"].startswith("dm_")        # (at this test's 4 samples the projections' dm_gemm can outweigh the scans)
     assert ("hipGraphs around the gradient all-reduce" in d["config"]["workload"]) == graph
+    assert d["comm"]["world"] == 1 and d["comm"]["bytes_all_reduced_per_step"] > 0
+    if not graph:
+        # a data-parallel run of the default model also times the reference's own regime as a leg of the SAME record: one sample per GPU,
+        # two hipGraphs around one gradient all-reduce, with its own comm block (what an 8-GPU run of the driver will report)
+        leg = d["configs"]["c3_one_sample_graph"]
+        assert leg["ms_per_step"] > 0 and leg["global_batch"] == 1 and "hipGraphs around the gradient all-reduce" in leg["workload"]
+        assert leg["comm"]["collectives_per_step"] == 1 and d["roofline"]["configs"]["c3_one_sample_graph"]["ms_per_step"] == leg["ms_per_step"]
+    else:
+        assert "configs" not in d
 
 
 def test_graphed_train_step_two_graphs_equal_one_graph(gpu, monkeypatch):
